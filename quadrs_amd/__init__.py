@@ -1,0 +1,13 @@
+"""quadrs_amd — MI355X (gfx950) engine for quadrs' IQ-stream hot path.
+
+The product is quadrs_amd/libquadrs_hip.so (hand-written HIP kernels behind the C ABI in
+include/quadrs_hip.h).  This package is the thin Python view of that ABI used by tests and
+bench.py; it mirrors the reference's operator names (from / shift / lowpass / sparkfft /
+bucket / gen) and error behaviour.  It never computes on the CPU: if the HIP library is
+missing, importing `quadrs_amd.engine` objects raises.
+"""
+from . import _ffi  # noqa: F401
+from .engine import (Plan, fft_norm_batch, gen, lowpass_block, lowpass_design, shift, shift_ratio,  # noqa: F401
+                     unpack)
+from ._ffi import (EPI_BUCKET2_U8, EPI_GLYPH_U8, EPI_NORMS_F32, FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8,  # noqa: F401
+                   QuadrsError)

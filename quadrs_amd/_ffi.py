@@ -1,0 +1,94 @@
+"""ctypes binding of include/quadrs_hip.h (the C ABI).  No torch types cross this boundary:
+device buffers are passed as integer addresses (e.g. tensor.data_ptr())."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libquadrs_hip.so")
+
+OK, ERR_INVALID, ERR_PANIC, ERR_SHORT, ERR_HIP, ERR_UNSUPPORTED = range(6)
+FMT_CF32, FMT_CS8, FMT_CU8, FMT_CS16 = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+EPI_NORMS_F32, EPI_GLYPH_U8, EPI_BUCKET2_U8 = 0, 1, 2
+
+# every symbol include/quadrs_hip.h declares
+SYMBOLS = [
+    "qd_last_error", "qd_version", "qd_device_count", "qd_set_device", "qd_pair_bytes", "qd_unpack",
+    "qd_shift_ratio", "qd_shift", "qd_lowpass_design", "qd_lowpass_block", "qd_fft_norm_batch",
+    "qd_plan_create", "qd_plan_destroy", "qd_plan_get_info", "qd_plan_get_taps", "qd_plan_src_range",
+    "qd_plan_run", "qd_plan_set_timing", "qd_plan_last_kernel_ms", "qd_gen",
+]
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("format", C.c_int32), ("sample_rate", C.c_uint64),
+        ("n_samples", C.c_uint64), ("has_shift", C.c_int32), ("_pad0", C.c_int32),
+        ("shift_hz", C.c_int64), ("has_lowpass", C.c_int32), ("_pad1", C.c_int32),
+        ("lowpass_hz", C.c_uint64), ("decimate", C.c_uint64), ("taps", C.c_uint64),
+        ("width", C.c_uint64), ("stride", C.c_uint64), ("epilogue", C.c_int32),
+        ("has_range", C.c_int32), ("range_min", C.c_float), ("range_max", C.c_float),
+    ]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [
+        ("n_windows", C.c_uint64), ("decimated_len", C.c_uint64), ("out_sample_rate", C.c_uint64),
+        ("out_bytes_per_window", C.c_uint64), ("raw_per_window", C.c_uint64), ("raw_step", C.c_uint64),
+        ("ratio", C.c_double), ("tile_windows", C.c_uint32), ("threads", C.c_uint32),
+        ("lds_bytes", C.c_uint32), ("_pad", C.c_uint32),
+    ]
+
+
+class QuadrsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"quadrs-hip status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension.  There is no CPU fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python quadrs_amd/build.py` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, u64, i64, sz, f32, f64, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_size_t, C.c_float, C.c_double, C.c_int
+        sig = {
+            "qd_last_error": (C.c_char_p, []),
+            "qd_version": (C.c_char_p, []),
+            "qd_device_count": (i32, [C.POINTER(i32)]),
+            "qd_set_device": (i32, [i32]),
+            "qd_pair_bytes": (u64, [i32]),
+            "qd_unpack": (i32, [i32, vp, sz, vp, i32]),
+            "qd_shift_ratio": (f64, [i64, u64]),
+            "qd_shift": (i32, [vp, sz, u64, f64, i32]),
+            "qd_lowpass_design": (i32, [u64, u64, sz, vp]),
+            "qd_lowpass_block": (i32, [vp, sz, u64, vp, sz, vp, sz, C.POINTER(sz), i32]),
+            "qd_fft_norm_batch": (i32, [vp, sz, sz, sz, vp, i32]),
+            "qd_plan_create": (i32, [C.POINTER(ChainDesc), C.POINTER(vp)]),
+            "qd_plan_destroy": (i32, [vp]),
+            "qd_plan_get_info": (i32, [vp, C.POINTER(PlanInfo)]),
+            "qd_plan_get_taps": (i32, [vp, vp, sz]),
+            "qd_plan_src_range": (i32, [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]),
+            "qd_plan_run": (i32, [vp, vp, i32, u64, u64, u64, u64, vp, i32, vp]),
+            "qd_plan_set_timing": (i32, [vp, i32]),
+            "qd_plan_last_kernel_ms": (i32, [vp, C.POINTER(f32)]),
+            "qd_gen": (i32, [vp, sz, u64, u64, sz, vp, i32]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != OK:
+        raise QuadrsError(code, lib().qd_last_error().decode(errors="replace"))

@@ -1,0 +1,167 @@
+// qd_device.h — device-side arithmetic shared by every kernel of the engine (gfx950 only).
+//
+// Everything here is written so that, compiled with -ffp-contract=off, each f32 operation
+// rounds exactly where the reference's Rust code rounds (no FMA contraction anywhere on
+// the f32 data path).  f64 fma() calls in the NCO are explicit and intentional.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qd {
+
+// ---------------------------------------------------------------- complex f32 (num-complex 0.4.6)
+
+// Complex<f32> * Complex<f32>: (a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re)
+// reference: src/shift.rs:51 (`buf[i] *= mul`), rustfft twiddle products.
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    float2 r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// rustfft twiddles::rotate_90, Forward: (im, -re)
+__device__ __forceinline__ float2 rot90(float2 v) { return make_float2(v.y, -v.x); }
+
+// num-complex norm() = re.hypot(im) -> glibc 2.35 __hypotf, which is
+// (float)sqrt((double)x*x + (double)y*y) with inf/nan screened first (checked bit-for-bit
+// against glibc on 2e8 random pairs).  reference: src/fft.rs:53,95-96.
+__device__ __forceinline__ float norm_ref(float2 v) {
+    float x = v.x, y = v.y;
+    if (!(__builtin_isfinite(x) && __builtin_isfinite(y))) {
+        if (__builtin_isinf(x) || __builtin_isinf(y)) return __builtin_inff();
+        return x + y;
+    }
+    double dx = (double)x, dy = (double)y;
+    return (float)__builtin_sqrt(dx * dx + dy * dy);
+}
+
+// ---------------------------------------------------------------- unpack (src/lib.rs:241-255)
+
+// one IEEE f32 division (+ one IEEE subtraction); hipcc's default f32 '/' is correctly rounded
+__device__ __forceinline__ float unpack_cs8(uint32_t b) { return (float)(int8_t)(uint8_t)b / 127.0f; }
+__device__ __forceinline__ float unpack_cu8(uint32_t b) {
+    float q = (float)(uint8_t)b / 255.0f;
+    return q - 127.5f;
+}
+__device__ __forceinline__ float unpack_cs16(uint32_t h) {
+    float q = (float)(int16_t)(uint16_t)h / 65535.0f;
+    return q - 32767.5f;
+}
+
+// ---------------------------------------------------------------- glyph (src/fft.rs:45,54-60)
+
+__device__ __forceinline__ uint8_t glyph_code(float norm, float mn, float mx) {
+    float distinction = (mx - mn) / 7.0f;
+    if (norm < mn) return 0;
+    if (norm >= mx) return 8;
+    float f = (norm - mn) / distinction;
+    // Rust `as usize`: saturating, NaN -> 0
+    if (!(f > 0.0f)) return 1;
+    if (f >= 7.0f) return 255;   // graph[7]: the reference panics here
+    return (uint8_t)(1 + (uint32_t)f);
+}
+
+// ---------------------------------------------------------------- FFT butterflies (rustfft 6.4.0 scalar)
+
+__device__ __forceinline__ void bf2(float2 &l, float2 &r) {
+    float2 t = cadd(l, r);
+    r = csub(l, r);
+    l = t;
+}
+
+// Butterfly4::perform_fft_contiguous
+__device__ __forceinline__ void bf4(float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+    float2 v0 = x0, v1 = x1, v2 = x2, v3 = x3;
+    bf2(v0, v2);
+    bf2(v1, v3);
+    v3 = rot90(v3);
+    bf2(v0, v1);
+    bf2(v2, v3);
+    x0 = v0; x1 = v2; x2 = v1; x3 = v3;
+}
+
+// Butterfly8::perform_fft_contiguous
+__device__ __forceinline__ void bf8(float2 *v, float root2) {
+    float2 a0 = v[0], a1 = v[2], a2 = v[4], a3 = v[6];
+    float2 b0 = v[1], b1 = v[3], b2 = v[5], b3 = v[7];
+    bf4(a0, a1, a2, a3);
+    bf4(b0, b1, b2, b3);
+    b1 = cscale(cadd(rot90(b1), b1), root2);
+    b2 = rot90(b2);
+    b3 = cscale(csub(rot90(b3), b3), root2);
+    bf2(a0, b0); bf2(a1, b1); bf2(a2, b2); bf2(a3, b3);
+    v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+    v[4] = b0; v[5] = b1; v[6] = b2; v[7] = b3;
+}
+
+// Butterfly16::perform_fft_contiguous (one hard-coded step of split radix)
+__device__ __forceinline__ void bf16(float2 *v, float2 tw1, float2 tw2, float2 tw3, float root2) {
+    float2 ev[8] = { v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14] };
+    float2 p0 = v[1], p1 = v[5], p2 = v[9], p3 = v[13];
+    float2 q0 = v[15], q1 = v[3], q2 = v[7], q3 = v[11];
+    bf8(ev, root2);
+    bf4(p0, p1, p2, p3);
+    bf4(q0, q1, q2, q3);
+    p1 = cmul(p1, tw1); q1 = cmul(q1, cconj(tw1));
+    p2 = cmul(p2, tw2); q2 = cmul(q2, cconj(tw2));
+    p3 = cmul(p3, tw3); q3 = cmul(q3, cconj(tw3));
+    bf2(p0, q0); bf2(p1, q1); bf2(p2, q2); bf2(p3, q3);
+    q0 = rot90(q0); q1 = rot90(q1); q2 = rot90(q2); q3 = rot90(q3);
+    v[0] = cadd(ev[0], p0); v[1] = cadd(ev[1], p1); v[2] = cadd(ev[2], p2); v[3] = cadd(ev[3], p3);
+    v[4] = cadd(ev[4], q0); v[5] = cadd(ev[5], q1); v[6] = cadd(ev[6], q2); v[7] = cadd(ev[7], q3);
+    v[8] = csub(ev[0], p0); v[9] = csub(ev[1], p1); v[10] = csub(ev[2], p2); v[11] = csub(ev[3], p3);
+    v[12] = csub(ev[4], q0); v[13] = csub(ev[5], q1); v[14] = csub(ev[6], q2); v[15] = csub(ev[7], q3);
+}
+
+// reverse the `digits` base-4 digits of x
+__device__ __forceinline__ uint32_t rev4(uint32_t x, uint32_t digits) {
+    uint32_t r = 0;
+    for (uint32_t d = 0; d < digits; ++d) { r = (r << 2) | (x & 3u); x >>= 2; }
+    return r;
+}
+
+// ---------------------------------------------------------------- NCO (src/shift.rs:49-50)
+
+// Row-base entry: everything that is uniform over one row of ROW consecutive samples.
+struct __attribute__((aligned(32))) RowBase {
+    double c, s;     // cos/sin of theta
+    double theta;    // fl((double)(row*ROW) * ratio)  — the reference's `place` at the row start
+    double nf;       // (double)(row*ROW)
+};
+
+// Per-lane constants for one sample slot j inside a row: tj = fl(j*ratio), cos/sin(tj).
+struct LaneRot { double jf, tj, c, s; };
+
+// Multiplier (cos(place) as f32, sin(place) as f32) with place = fl((double)n * ratio),
+// n = row start + j.  place is formed exactly as the reference forms it; its cosine/sine are
+// obtained by rotating the row base by d = place - theta_row (an exact f64 difference),
+// d = tj + e with |e| <= ~ulp(place): cos/sin(d) from the lane constants plus a first or
+// second order correction in e.  Total error ~4e-16, so the f32 rounding equals glibc's
+// except when the f64 value lies within ~1e-8 f32-ulp of a rounding boundary.
+__device__ __forceinline__ float2 nco_mul(const RowBase &rb, const LaneRot &lr, double ratio, bool second_order) {
+    double nf = rb.nf + lr.jf;          // exact (integers < 2^53)
+    double place = nf * ratio;          // == reference `place`
+    double d = place - rb.theta;        // exact (Sterbenz)
+    double e = d - lr.tj;               // exact
+    double cd, sd;
+    if (second_order) {
+        double h = 0.5 * e;
+        double u = __builtin_fma(h, lr.c, lr.s);
+        double v = __builtin_fma(-h, lr.s, lr.c);
+        cd = __builtin_fma(-e, u, lr.c);
+        sd = __builtin_fma(e, v, lr.s);
+    } else {
+        cd = __builtin_fma(-e, lr.s, lr.c);
+        sd = __builtin_fma(e, lr.c, lr.s);
+    }
+    double c = __builtin_fma(-rb.s, sd, rb.c * cd);
+    double s = __builtin_fma(rb.c, sd, rb.s * cd);
+    return make_float2((float)c, (float)s);
+}
+
+}  // namespace qd

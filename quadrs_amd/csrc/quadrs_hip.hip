@@ -1,0 +1,735 @@
+// quadrs_hip.hip — C ABI (include/quadrs_hip.h) + host-side planning for the gfx950 engine.
+//
+// Host responsibilities (all O(plan), none per-sample): validate the chain the way the
+// reference's constructors do, design the taps with the platform libm (src/filter.rs:86-105 —
+// the reference does this on the host too), lay out twiddles, build the NCO tables on the
+// device, pick the tile geometry, launch.  Per-sample work lives in qd_chain.h / qd_device.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/quadrs_hip.h"
+#include "qd_chain.h"
+
+using namespace qd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) return fail(QD_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+constexpr double kPi64 = 3.14159265358979323846264338327950288;
+constexpr float kPi32 = 3.14159265358979323846264338327950288f;
+
+uint32_t ilog2(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) ++l; return l; }
+bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
+
+int spl_of(int fmt) { return fmt == QD_FMT_CF32 ? 2 : 4; }
+int bps_of(int fmt) { return fmt == QD_FMT_CF32 ? 8 : (fmt == QD_FMT_CS16 ? 4 : 2); }
+
+// ------------------------------------------------------------------ small kernels
+
+// Row bases: (cos, sin)(fl((double)(row*ROW) * ratio)), plus theta and nf themselves.
+__global__ void k_rowtab(double ratio, uint32_t row_len, uint64_t row0, uint64_t n_rows, RowBase *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    double nf = (double)((row0 + i) * (uint64_t)row_len);
+    double th = nf * ratio;
+    double s, c;
+    sincos(th, &s, &c);
+    RowBase rb;
+    rb.c = c; rb.s = s; rb.theta = th; rb.nf = nf;
+    out[i] = rb;
+}
+
+__global__ void k_jtab(double ratio, uint32_t n, double2 *out) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double tj = (double)j * ratio;
+    double s, c;
+    sincos(tj, &s, &c);
+    out[j] = make_double2(c, s);
+}
+
+// FileFormat::to_cf32 per sample (src/lib.rs:231-255)
+__global__ void k_unpack(int fmt, const uint8_t *src, size_t n, float2 *out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float2 v;
+        switch (fmt) {
+        case 0: v = *reinterpret_cast<const float2 *>(src + i * 8); break;
+        case 1: { uint16_t w = *reinterpret_cast<const uint16_t *>(src + i * 2); v = make_float2(unpack_cs8(w & 0xff), unpack_cs8(w >> 8)); break; }
+        case 2: { uint16_t w = *reinterpret_cast<const uint16_t *>(src + i * 2); v = make_float2(unpack_cu8(w & 0xff), unpack_cu8(w >> 8)); break; }
+        default: { uint32_t w = *reinterpret_cast<const uint32_t *>(src + i * 4); v = make_float2(unpack_cs16(w & 0xffffu), unpack_cs16(w >> 16)); break; }
+        }
+        out[i] = v;
+    }
+}
+
+// Shift::read_at's loop over an arbitrary block (src/shift.rs:48-52), rows of 512 samples.
+__global__ __launch_bounds__(256) void k_shift(float2 *buf, uint64_t abs_off, uint64_t n, double ratio,
+                                                const RowBase *rowtab, uint64_t row0, uint64_t n_rows,
+                                                const double2 *jtab, int second_order) {
+    constexpr uint32_t ROW = 512;
+    const uint32_t tid = threadIdx.x;
+    LaneRot lr[2];
+    for (int u = 0; u < 2; ++u) {
+        uint32_t j = tid * 2 + u;
+        double2 cs = jtab[j];
+        lr[u].jf = (double)j; lr[u].tj = lr[u].jf * ratio; lr[u].c = cs.x; lr[u].s = cs.y;
+    }
+    for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const RowBase rb = rowtab[r];
+        for (int u = 0; u < 2; ++u) {
+            uint64_t idx = (row0 + r) * ROW + tid * 2 + u;
+            if (idx >= abs_off && idx < abs_off + n) {
+                float2 m = nco_mul(rb, lr[u], ratio, second_order != 0);
+                buf[idx - abs_off] = cmul(buf[idx - abs_off], m);
+            }
+        }
+    }
+}
+
+// LowPass::read_at on a fetched block (src/filter.rs:68-83,107-124): one lane per kept output.
+__global__ void k_lowpass_block(const float *__restrict__ taps, uint32_t T, uint64_t D, const float2 *__restrict__ raw,
+                                uint64_t valid, float2 *out, uint64_t out_n) {
+    const uint64_t c = T - T / 2;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < out_n; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t base = k * D + c;
+        uint64_t jmax = valid - base < T ? valid - base : T;
+        float ar = 0.f, ai = 0.f;
+        for (uint64_t j = 0; j < jmax; ++j) {
+            float2 x = raw[base + j];
+            float h = taps[j];
+            ar = ar + x.x * h;
+            ai = ai + x.y * h;
+        }
+        out[k] = make_float2(ar, ai);
+    }
+}
+
+// Gen::read_at (src/gen.rs:35-47)
+__global__ void k_gen(const int64_t *cos_hz, uint32_t n_cos, uint64_t sample_rate, uint64_t first, size_t n, float2 *out) {
+    const double tau = kPi64 * 2.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double base = (double)(first + i) * tau / (double)sample_rate;
+        float vr = 0.f, vi = 0.f;
+        for (uint32_t k = 0; k < n_cos; ++k) {
+            double f = (double)cos_hz[k] * base;
+            double s, c;
+            sincos(f, &s, &c);
+            vr = vr + (float)c;
+            vi = vi + (float)s;
+        }
+        out[i] = make_float2(vr, vi);
+    }
+}
+
+// ------------------------------------------------------------------ host arithmetic restated from the reference
+
+// src/filter.rs:86-105 with cutoff from :126-128,:31 — f32 throughout, platform libm
+void design_taps(uint64_t frequency, uint64_t sample_rate, size_t size, float *out) {
+    float cutoff = (float)((double)frequency / (double)sample_rate);
+    float sz1 = (float)size - 1.0f;
+    for (size_t i = 0; i < size; ++i) {
+        float fi = (float)i;
+        float a1 = (2.0f * kPi32) * fi / sz1;
+        float a2 = (4.0f * kPi32) * fi / sz1;
+        float window = 0.42f - 0.5f * std::cos(a1) + 0.08f * std::cos(a2);
+        float x = 2.0f * cutoff * (fi - sz1 / 2.0f);
+        float xp = x * kPi32;
+        float wave = std::sin(xp) / xp;
+        out[i] = wave * window;
+    }
+    float sum = 0.0f;
+    for (size_t i = 0; i < size; ++i) sum += out[i];
+    for (size_t i = 0; i < size; ++i) out[i] = out[i] / sum;
+}
+
+// rustfft twiddles::compute_twiddle, Forward
+float2 compute_twiddle(size_t index, size_t fft_len) {
+    double constant = -2.0 * kPi64 / (double)fft_len;
+    double angle = constant * (double)index;
+    return make_float2((float)std::cos(angle), (float)std::sin(angle));
+}
+
+struct FftLayout {
+    uint32_t base_len = 1, log_base = 0, layers = 0;
+    std::vector<float2> tw;
+};
+
+// Radix4::new: exponent 0..3 -> base 1,2,4,8; else odd -> 8, even -> 16
+FftLayout fft_layout(uint64_t W) {
+    FftLayout L;
+    uint32_t e = ilog2(W);
+    uint32_t be = e <= 3 ? e : ((e & 1) ? 3 : 4);
+    L.log_base = be; L.base_len = 1u << be; L.layers = (e - be) / 2;
+    size_t cross = L.base_len;
+    while (cross < W) {
+        size_t cols = cross;
+        cross *= 4;
+        for (size_t i = 0; i < cols; ++i)
+            for (size_t k = 1; k < 4; ++k) L.tw.push_back(compute_twiddle(i * k, cross));
+    }
+    return L;
+}
+
+typedef void (*chain_fn)(const ChainParams);
+
+chain_fn pick_kernel(int fmt, bool shift, bool fir) {
+#define QD_PICK(F)                                                                \
+    case F:                                                                       \
+        return shift ? (fir ? k_chain<F, true, true> : k_chain<F, true, false>)   \
+                     : (fir ? k_chain<F, false, true> : k_chain<F, false, false>);
+    switch (fmt) {
+        QD_PICK(0) QD_PICK(1) QD_PICK(2) QD_PICK(3)
+    }
+#undef QD_PICK
+    return nullptr;
+}
+
+struct Geometry {
+    uint32_t G = 1, Dp = 1, lds_raw_elems = 0;
+    size_t lds_bytes = 0;
+};
+
+size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems) {
+    uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
+    uint64_t pad = (D % 2 == 0) ? tile_raw / D + 1 : 0;
+    uint64_t elems = tile_raw + pad + 1;
+    uint64_t min_elems = (uint64_t)G * W / 2 + 1;     // bucket epilogue parks G*W f32 norms here
+    if (elems < min_elems) elems = min_elems;
+    elems = (elems + 1) & ~1ull;                      // keep fb 16-byte aligned
+    if (raw_elems) *raw_elems = (uint32_t)elems;
+    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + 256 * 4);
+}
+
+constexpr size_t kLdsMax = 160 * 1024;
+
+}  // namespace
+
+// ------------------------------------------------------------------ plan
+
+struct qd_plan {
+    qd_chain_desc d{};
+    int device = 0;
+    bool has_shift = false, has_fir = false;
+    uint32_t W = 0, logW = 0, S = 0, D = 1, T = 0;
+    uint64_t dec_len = 0, n_windows = 0, out_rate = 0;
+    double ratio = 0.0;
+    std::vector<float> taps_h;
+    float *taps_d = nullptr;
+    FftLayout fft;
+    float2 *tw_d = nullptr;
+    Geometry geo;
+    chain_fn fn = nullptr;
+    int wg_per_cu = 1, n_cu = 256;
+    // NCO tables
+    double2 *jtab_d = nullptr;
+    RowBase *rowtab_d = nullptr;
+    uint64_t rowtab_row0 = 0, rowtab_rows = 0;
+    // timing
+    bool timing = false, ev_made = false, ev_recorded = false;
+    hipEvent_t ev0{}, ev1{};
+    // host streaming
+    void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+    void *dev_in[2] = {nullptr, nullptr}, *dev_out[2] = {nullptr, nullptr};
+    size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    hipStream_t streams[2] = {nullptr, nullptr};
+    std::mutex mu;
+};
+
+namespace {
+
+uint64_t out_bytes_per_window(const qd_plan *p) {
+    switch (p->d.epilogue) {
+    case QD_EPI_NORMS_F32: return (uint64_t)p->W * 4;
+    case QD_EPI_GLYPH_U8: return p->W;
+    default: return 1;
+    }
+}
+
+int ensure_rowtab(qd_plan *p, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
+    if (!p->has_shift) return QD_OK;
+    const uint32_t ROW = kThreads * spl_of(p->d.format);
+    uint64_t r_lo = n_lo / ROW, r_hi = (n_hi + ROW - 1) / ROW + 1;
+    if (p->rowtab_d && r_lo >= p->rowtab_row0 && r_hi <= p->rowtab_row0 + p->rowtab_rows) return QD_OK;
+    if (p->rowtab_d) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(p->rowtab_d)); p->rowtab_d = nullptr; }
+    uint64_t rows = r_hi - r_lo;
+    HIPCHK(hipMalloc(&p->rowtab_d, rows * sizeof(RowBase)));
+    p->rowtab_row0 = r_lo; p->rowtab_rows = rows;
+    uint32_t blocks = (uint32_t)((rows + 255) / 256);
+    hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, p->rowtab_d);
+    HIPCHK(hipGetLastError());
+    return QD_OK;
+}
+
+int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src_count, uint64_t first_window,
+                 uint64_t n_windows, uint64_t out_window0, void *out_d, hipStream_t st) {
+    if (n_windows == 0) return QD_OK;
+    const int fmt = p->d.format;
+    const int spl = spl_of(fmt), bps = bps_of(fmt);
+    uint64_t need0 = first_window * p->S * p->D;
+    uint64_t need1 = (first_window + n_windows - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
+    if (need0 < src_first || need1 > src_first + src_count)
+        return fail(QD_ERR_INVALID, "src slab [%llu,+%llu) does not cover samples [%llu,%llu) needed by windows [%llu,+%llu)",
+                    (unsigned long long)src_first, (unsigned long long)src_count, (unsigned long long)need0,
+                    (unsigned long long)need1, (unsigned long long)first_window, (unsigned long long)n_windows);
+    int rc = ensure_rowtab(p, need0, need1, st);
+    if (rc) return rc;
+
+    ChainParams P{};
+    P.src = static_cast<const uint8_t *>(src_d);
+    P.src_first = src_first; P.src_count = src_count;
+    P.first_window = first_window; P.n_windows = n_windows; P.out_window0 = out_window0;
+    P.W = p->W; P.logW = p->logW; P.S = p->S; P.D = p->D; P.T = p->T; P.c = p->T - p->T / 2;
+    P.G = p->geo.G; P.Dp = p->geo.Dp;
+    P.dmagic = p->D > 1 ? (uint32_t)((1ull << 32) / p->D + 1) : 0;
+    P.a0 = P.c / p->D; P.b0 = P.c % p->D;
+    uint32_t tfast = p->D + p->T / 2;
+    P.T_fast = tfast < p->T ? tfast : p->T;
+    P.a1 = (P.c + P.T_fast) / p->D; P.b1 = (P.c + P.T_fast) % p->D;
+    P.base_len = p->fft.base_len; P.log_base = p->fft.log_base; P.layers = p->fft.layers;
+    const int vec_bytes = spl * bps;
+    P.vec_ok = ((reinterpret_cast<uintptr_t>(src_d) % vec_bytes) == 0 && (src_first % spl) == 0) ? 1 : 0;
+    // |place| = n*|ratio|; second-order NCO term matters once ulp(place)^2/2 approaches 1e-16
+    P.second_order = (std::fabs(p->ratio) * (double)need1 > 67108864.0) ? 1 : 0;
+    P.epi = (uint32_t)p->d.epilogue;
+    P.lds_raw_elems = p->geo.lds_raw_elems;
+    P.rmin = p->d.has_range ? p->d.range_min : 0.08f;     // src/fft.rs:22-23
+    P.rmax = p->d.has_range ? p->d.range_max : 1.0f;
+    P.root2 = (float)std::sqrt(0.5);
+    P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
+    P.ratio = p->ratio;
+    P.rowtab = p->rowtab_d; P.rowtab_row0 = p->rowtab_row0;
+    P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
+    P.out = out_d;
+
+    uint64_t n_tiles = (n_windows + P.G - 1) / P.G;
+    uint64_t cap = (uint64_t)p->n_cu * p->wg_per_cu;
+    uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
+    if (p->timing) {
+        if (!p->ev_made) { HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1)); p->ev_made = true; }
+        HIPCHK(hipEventRecord(p->ev0, st));
+    }
+    hipLaunchKernelGGL(p->fn, dim3(grid), dim3(kThreads), p->geo.lds_bytes, st, P);
+    HIPCHK(hipGetLastError());
+    if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
+    return QD_OK;
+}
+
+void free_streaming(qd_plan *p) {
+    for (int i = 0; i < 2; ++i) {
+        if (p->pin_in[i]) (void)hipHostFree(p->pin_in[i]);
+        if (p->pin_out[i]) (void)hipHostFree(p->pin_out[i]);
+        if (p->dev_in[i]) (void)hipFree(p->dev_in[i]);
+        if (p->dev_out[i]) (void)hipFree(p->dev_out[i]);
+        if (p->streams[i]) (void)hipStreamDestroy(p->streams[i]);
+        p->pin_in[i] = p->pin_out[i] = p->dev_in[i] = p->dev_out[i] = nullptr;
+        p->streams[i] = nullptr;
+    }
+    p->stage_in_bytes = p->stage_out_bytes = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *qd_last_error(void) { return g_err.c_str(); }
+const char *qd_version(void) { return "quadrs-hip 0.1 (gfx950)"; }
+
+int qd_device_count(int *count) {
+    if (!count) return fail(QD_ERR_INVALID, "count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return QD_OK;
+}
+
+int qd_set_device(int device) {
+    HIPCHK(hipSetDevice(device));
+    return QD_OK;
+}
+
+uint64_t qd_pair_bytes(int fmt) {
+    switch (fmt) {
+    case QD_FMT_CF32: return 8;
+    case QD_FMT_CS8: case QD_FMT_CU8: return 2;
+    case QD_FMT_CS16: return 4;
+    }
+    return 0;
+}
+
+double qd_shift_ratio(int64_t frequency, uint64_t sample_rate) {
+    return (kPi64 * 2.0) * (double)frequency / (double)sample_rate;   // src/shift.rs:28, src/lib.rs:23
+}
+
+int qd_lowpass_design(uint64_t frequency, uint64_t sample_rate, size_t size, float *taps) {
+    if (!taps) return fail(QD_ERR_INVALID, "taps is NULL");
+    design_taps(frequency, sample_rate, size, taps);
+    return QD_OK;
+}
+
+int qd_plan_destroy(qd_plan *p);
+
+static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t rate) {
+    (void)hipGetDevice(&p->device);
+    p->has_shift = d.has_shift != 0;
+    p->has_fir = d.has_lowpass != 0;
+    p->W = (uint32_t)d.width; p->logW = ilog2(d.width); p->S = (uint32_t)d.stride;
+    p->D = p->has_fir ? (uint32_t)d.decimate : 1;
+    p->T = p->has_fir ? (uint32_t)d.taps : 0;
+    p->dec_len = len; p->out_rate = rate;
+    uint64_t lim = len - d.width;
+    if (d.epilogue == QD_EPI_BUCKET2_U8) p->n_windows = lim / d.stride;                 // src/fft.rs:86
+    else p->n_windows = lim == 0 ? 0 : (lim - 1) / d.stride + 1;                        // src/fft.rs:28,65
+    p->ratio = p->has_shift ? qd_shift_ratio(d.shift_hz, d.sample_rate) : 0.0;
+
+    // tile geometry
+    uint32_t G = 1, raw_elems = 0;
+    if (lds_for(1, p->W, p->S, p->D, p->T, &raw_elems) > kLdsMax) {
+        return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
+                    (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
+    }
+    while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 40 * 1024) G *= 2;
+    while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 36 * 1024) G *= 2;
+    if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
+    p->geo.G = G;
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, p->T, &raw_elems);
+    p->geo.lds_raw_elems = raw_elems;
+    p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
+    if ((uint64_t)raw_elems * p->D >= (1ull << 32)) { return fail(QD_ERR_UNSUPPORTED, "tile too large"); }
+
+    p->fn = pick_kernel(d.format, p->has_shift, p->has_fir);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->n_cu = prop.multiProcessorCount;
+    int by_lds = (int)(kLdsMax / p->geo.lds_bytes);
+    p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p->fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)p->geo.lds_bytes);
+    if (e != hipSuccess) { return fail(QD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS %zu): %s", p->geo.lds_bytes, hipGetErrorString(e)); }
+
+    // constant tables
+    p->fft = fft_layout(d.width);
+    if (!p->fft.tw.empty()) {
+        HIPCHK(hipMalloc(&p->tw_d, p->fft.tw.size() * sizeof(float2)));
+        HIPCHK(hipMemcpy(p->tw_d, p->fft.tw.data(), p->fft.tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    if (p->has_fir) {
+        p->taps_h.resize(p->T);
+        design_taps(d.lowpass_hz, d.sample_rate, p->T, p->taps_h.data());
+        HIPCHK(hipMalloc(&p->taps_d, p->T * sizeof(float)));
+        HIPCHK(hipMemcpy(p->taps_d, p->taps_h.data(), p->T * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (p->has_shift) {
+        const uint32_t ROW = kThreads * spl_of(d.format);
+        HIPCHK(hipMalloc(&p->jtab_d, ROW * sizeof(double2)));
+        hipLaunchKernelGGL(k_jtab, dim3((ROW + 255) / 256), dim3(256), 0, 0, p->ratio, ROW, p->jtab_d);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+    }
+    return QD_OK;
+}
+
+
+int qd_plan_create(const qd_chain_desc *desc, qd_plan **out) {
+    if (!desc || !out) return fail(QD_ERR_INVALID, "desc/plan is NULL");
+    if (desc->struct_size != sizeof(qd_chain_desc)) return fail(QD_ERR_INVALID, "qd_chain_desc size mismatch");
+    const qd_chain_desc &d = *desc;
+    if (d.format < 0 || d.format > 3) return fail(QD_ERR_INVALID, "unknown format %d", d.format);
+    if (d.epilogue < 0 || d.epilogue > 2) return fail(QD_ERR_INVALID, "unknown epilogue %d", d.epilogue);
+    if (!is_pow2(d.width))
+        return fail(QD_ERR_PANIC, "Radix4 requires a power-of-two width (rustfft API contract), got %llu", (unsigned long long)d.width);
+    if (d.width > (1u << 20)) return fail(QD_ERR_UNSUPPORTED, "width too large");
+    if (d.stride == 0) return fail(QD_ERR_INVALID, "stride 0 never terminates in the reference (src/fft.rs:65)");
+    if (d.stride > 0xffffffffull) return fail(QD_ERR_UNSUPPORTED, "stride too large");
+    uint64_t len = d.n_samples, rate = d.sample_rate;
+    if (d.has_shift) {
+        // Shift::new asserts, src/shift.rs:20-24
+        int64_t af = d.shift_hz < 0 ? -d.shift_hz : d.shift_hz;
+        if (!(af < (int64_t)(d.sample_rate / 2)) || d.sample_rate == 0)
+            return fail(QD_ERR_PANIC, "frequency must be under half the sample rate (src/shift.rs:20-24)");
+    }
+    if (d.has_lowpass) {
+        if (d.decimate == 0) return fail(QD_ERR_PANIC, "decimate 0 divides by zero (src/filter.rs:47)");
+        if (d.taps < 2) return fail(QD_ERR_PANIC, "lowpass size < 2 underflows (src/filter.rs:74)");
+        if (d.taps > 65536 || d.decimate > 65536) return fail(QD_ERR_UNSUPPORTED, "taps/decimate too large");
+        if (len < d.taps) return fail(QD_ERR_PANIC, "inner.len() < filter.len() (src/filter.rs:46)");
+        len = 1 + (len - d.taps) / d.decimate;     // LowPass::len, src/filter.rs:47
+        rate = rate / d.decimate;                  // src/filter.rs:51
+    }
+    if (len < d.width) return fail(QD_ERR_PANIC, "len %llu < width %llu: u64 underflow at src/fft.rs:28,86",
+                                   (unsigned long long)len, (unsigned long long)d.width);
+    qd_plan *p = new qd_plan();
+    p->d = d;
+    int rc = plan_init(p, d, len, rate);
+    if (rc) { qd_plan_destroy(p); return rc; }
+    *out = p;
+    return QD_OK;
+}
+
+int qd_plan_destroy(qd_plan *p) {
+    if (!p) return QD_OK;
+    (void)hipDeviceSynchronize();
+    free_streaming(p);
+    if (p->taps_d) (void)hipFree(p->taps_d);
+    if (p->tw_d) (void)hipFree(p->tw_d);
+    if (p->jtab_d) (void)hipFree(p->jtab_d);
+    if (p->rowtab_d) (void)hipFree(p->rowtab_d);
+    if (p->ev_made) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
+    delete p;
+    return QD_OK;
+}
+
+int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
+    if (!p || !info) return fail(QD_ERR_INVALID, "plan/info is NULL");
+    memset(info, 0, sizeof *info);
+    info->n_windows = p->n_windows;
+    info->decimated_len = p->dec_len;
+    info->out_sample_rate = p->out_rate;
+    info->out_bytes_per_window = out_bytes_per_window(p);
+    info->raw_per_window = (uint64_t)p->W * p->D + p->T;
+    info->raw_step = (uint64_t)p->S * p->D;
+    info->ratio = p->ratio;
+    info->tile_windows = p->geo.G;
+    info->threads = kThreads;
+    info->lds_bytes = (uint32_t)p->geo.lds_bytes;
+    return QD_OK;
+}
+
+int qd_plan_get_taps(const qd_plan *p, float *taps, size_t cap) {
+    if (!p || !taps) return fail(QD_ERR_INVALID, "plan/taps is NULL");
+    if (cap < p->taps_h.size()) return fail(QD_ERR_INVALID, "taps buffer too small");
+    if (!p->taps_h.empty()) memcpy(taps, p->taps_h.data(), p->taps_h.size() * sizeof(float));
+    return QD_OK;
+}
+
+int qd_plan_src_range(const qd_plan *p, uint64_t first_window, uint64_t n_windows, uint64_t *first, uint64_t *count) {
+    if (!p || !first || !count) return fail(QD_ERR_INVALID, "NULL argument");
+    if (n_windows == 0) { *first = first_window * p->S * p->D; *count = 0; return QD_OK; }
+    *first = first_window * p->S * p->D;
+    *count = (n_windows - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
+    return QD_OK;
+}
+
+int qd_plan_set_timing(qd_plan *p, int enabled) {
+    if (!p) return fail(QD_ERR_INVALID, "plan is NULL");
+    p->timing = enabled != 0;
+    return QD_OK;
+}
+
+int qd_plan_last_kernel_ms(qd_plan *p, float *ms) {
+    if (!p || !ms) return fail(QD_ERR_INVALID, "NULL argument");
+    if (!p->ev_recorded) return fail(QD_ERR_INVALID, "no timed run recorded");
+    HIPCHK(hipEventSynchronize(p->ev1));
+    HIPCHK(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return QD_OK;
+}
+
+int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint64_t src_count,
+                uint64_t first_window, uint64_t n_windows, void *out, int out_mem, void *stream) {
+    if (!p || !src || !out) return fail(QD_ERR_INVALID, "NULL argument");
+    if (first_window + n_windows > p->n_windows)
+        return fail(QD_ERR_SHORT, "windows [%llu,+%llu) exceed the sink's loop (%llu windows)", (unsigned long long)first_window,
+                    (unsigned long long)n_windows, (unsigned long long)p->n_windows);
+    if (src_first + src_count > p->d.n_samples) return fail(QD_ERR_INVALID, "src slab exceeds the stream length");
+    std::lock_guard<std::mutex> lock(p->mu);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (src_mem == QD_MEM_DEVICE && out_mem == QD_MEM_DEVICE)
+        return launch_chain(p, src, src_first, src_count, first_window, n_windows, first_window, out, st);
+    if (src_mem != QD_MEM_HOST || out_mem != QD_MEM_HOST)
+        return fail(QD_ERR_UNSUPPORTED, "mixed host/device buffers are not supported; use both host or both device");
+
+    // host-resident stream: chunked, double-buffered H2D / kernel / D2H
+    const int bps = bps_of(p->d.format);
+    const uint64_t obw = out_bytes_per_window(p);
+    const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
+    const uint64_t target_bytes = 64ull << 20;
+    uint64_t cw = target_bytes / (step * bps ? step * bps : 1);
+    if (cw < p->geo.G) cw = p->geo.G;
+    cw = (cw / p->geo.G) * p->geo.G;
+    if (cw > n_windows) cw = n_windows ? n_windows : 1;
+    const size_t in_bytes = (size_t)(((cw - 1) * step + rpw + 8) * bps), ob = (size_t)(cw * obw);
+    if (in_bytes > p->stage_in_bytes || ob > p->stage_out_bytes) {
+        free_streaming(p);
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipHostMalloc(&p->pin_in[i], in_bytes, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc(&p->pin_out[i], ob, hipHostMallocDefault));
+            HIPCHK(hipMalloc(&p->dev_in[i], in_bytes));
+            HIPCHK(hipMalloc(&p->dev_out[i], ob));
+            HIPCHK(hipStreamCreateWithFlags(&p->streams[i], hipStreamNonBlocking));
+        }
+        p->stage_in_bytes = in_bytes; p->stage_out_bytes = ob;
+    }
+    struct Pending { bool live = false; uint64_t w0 = 0, nw = 0; } pend[2];
+    auto drain = [&](int slot) -> int {
+        if (!pend[slot].live) return QD_OK;
+        HIPCHK(hipStreamSynchronize(p->streams[slot]));
+        memcpy(static_cast<uint8_t *>(out) + (pend[slot].w0 - first_window) * obw, p->pin_out[slot], pend[slot].nw * obw);
+        pend[slot].live = false;
+        return QD_OK;
+    };
+    int slot = 0;
+    for (uint64_t w = first_window; w < first_window + n_windows; w += cw, slot ^= 1) {
+        int rc = drain(slot);
+        if (rc) return rc;
+        uint64_t nw = first_window + n_windows - w < cw ? first_window + n_windows - w : cw;
+        uint64_t s0 = w * step, cnt = (nw - 1) * step + rpw;
+        // keep vector loads aligned: start the slab on a multiple of 8 samples
+        uint64_t s0a = s0 & ~7ull;
+        if (s0a < src_first) s0a = src_first;
+        uint64_t cnta = s0 + cnt - s0a;
+        if (s0a < src_first || s0a + cnta > src_first + src_count)
+            return fail(QD_ERR_INVALID, "src slab does not cover the requested windows");
+        memcpy(p->pin_in[slot], static_cast<const uint8_t *>(src) + (s0a - src_first) * bps, cnta * bps);
+        HIPCHK(hipMemcpyAsync(p->dev_in[slot], p->pin_in[slot], cnta * bps, hipMemcpyHostToDevice, p->streams[slot]));
+        rc = launch_chain(p, p->dev_in[slot], s0a, cnta, w, nw, w, p->dev_out[slot], p->streams[slot]);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(p->pin_out[slot], p->dev_out[slot], nw * obw, hipMemcpyDeviceToHost, p->streams[slot]));
+        pend[slot].live = true; pend[slot].w0 = w; pend[slot].nw = nw;
+    }
+    int rc = drain(0);
+    if (rc) return rc;
+    return drain(1);
+}
+
+// ------------------------------------------------------------------ fine-grained ops
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+int qd_unpack(int fmt, const void *bytes, size_t n_pairs, qd_c32 *out, int mem) {
+    if (fmt < 0 || fmt > 3) return fail(QD_ERR_INVALID, "unknown format %d", fmt);
+    if (n_pairs == 0) return QD_OK;
+    if (!bytes || !out) return fail(QD_ERR_INVALID, "NULL buffer");
+    const size_t ib = n_pairs * qd_pair_bytes(fmt), ob = n_pairs * 8;
+    DevBuf di, dout;
+    const void *src = bytes; void *dst = out;
+    if (mem == QD_MEM_HOST) {
+        HIPCHK(hipMalloc(&di.p, ib)); HIPCHK(hipMalloc(&dout.p, ob));
+        HIPCHK(hipMemcpy(di.p, bytes, ib, hipMemcpyHostToDevice));
+        src = di.p; dst = dout.p;
+    }
+    size_t blocks = (n_pairs + 255) / 256; if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_unpack, dim3((uint32_t)blocks), dim3(256), 0, 0, fmt, static_cast<const uint8_t *>(src), n_pairs,
+                       static_cast<float2 *>(dst));
+    HIPCHK(hipGetLastError());
+    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+    return QD_OK;
+}
+
+int qd_shift(qd_c32 *buf, size_t n, uint64_t abs_off, double ratio, int mem) {
+    if (n == 0) return QD_OK;
+    if (!buf) return fail(QD_ERR_INVALID, "NULL buffer");
+    constexpr uint32_t ROW = 512;
+    DevBuf db, rt, jt;
+    float2 *d = reinterpret_cast<float2 *>(buf);
+    if (mem == QD_MEM_HOST) {
+        HIPCHK(hipMalloc(&db.p, n * 8));
+        HIPCHK(hipMemcpy(db.p, buf, n * 8, hipMemcpyHostToDevice));
+        d = static_cast<float2 *>(db.p);
+    }
+    uint64_t r0 = abs_off / ROW, r1 = (abs_off + n + ROW - 1) / ROW, rows = r1 - r0;
+    HIPCHK(hipMalloc(&rt.p, rows * sizeof(RowBase)));
+    HIPCHK(hipMalloc(&jt.p, ROW * sizeof(double2)));
+    hipLaunchKernelGGL(k_rowtab, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, 0, ratio, ROW, r0, rows, static_cast<RowBase *>(rt.p));
+    hipLaunchKernelGGL(k_jtab, dim3(2), dim3(256), 0, 0, ratio, ROW, static_cast<double2 *>(jt.p));
+    int so = (std::fabs(ratio) * (double)(abs_off + n) > 67108864.0) ? 1 : 0;
+    uint32_t grid = (uint32_t)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL(k_shift, dim3(grid), dim3(256), 0, 0, d, abs_off, (uint64_t)n, ratio, static_cast<const RowBase *>(rt.p), r0, rows,
+                       static_cast<const double2 *>(jt.p), so);
+    HIPCHK(hipGetLastError());
+    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(buf, db.p, n * 8, hipMemcpyDeviceToHost));
+    else HIPCHK(hipDeviceSynchronize());   // tables are freed on return
+    return QD_OK;
+}
+
+int qd_lowpass_block(const float *taps, size_t T, uint64_t D, const qd_c32 *raw, size_t valid, qd_c32 *out,
+                     size_t out_cap, size_t *produced, int mem) {
+    if (!taps || !raw || !out || !produced) return fail(QD_ERR_INVALID, "NULL argument");
+    if (T < 2 || D == 0) return fail(QD_ERR_PANIC, "size < 2 or decimate 0 (src/filter.rs:47,74)");
+    if (valid < T) return fail(QD_ERR_PANIC, "valid < filter.len(): usize underflow at src/filter.rs:76");
+    size_t out_n = (size_t)((uint64_t)(valid - T) / D);
+    if (out_n > out_cap) return fail(QD_ERR_PANIC, "buf too small for %zu outputs (src/filter.rs:78-80)", out_n);
+    *produced = out_n;
+    if (out_n == 0) return QD_OK;
+    DevBuf dt, dr, dout;
+    HIPCHK(hipMalloc(&dt.p, T * 4));
+    HIPCHK(hipMemcpy(dt.p, taps, T * 4, hipMemcpyHostToDevice));   // taps are always host (O(T))
+    const float2 *r = reinterpret_cast<const float2 *>(raw);
+    float2 *o = reinterpret_cast<float2 *>(out);
+    if (mem == QD_MEM_HOST) {
+        HIPCHK(hipMalloc(&dr.p, valid * 8)); HIPCHK(hipMalloc(&dout.p, out_n * 8));
+        HIPCHK(hipMemcpy(dr.p, raw, valid * 8, hipMemcpyHostToDevice));
+        r = static_cast<const float2 *>(dr.p); o = static_cast<float2 *>(dout.p);
+    }
+    size_t blocks = (out_n + 127) / 128; if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_lowpass_block, dim3((uint32_t)blocks), dim3(128), 0, 0, static_cast<const float *>(dt.p), (uint32_t)T, D, r,
+                       (uint64_t)valid, o, (uint64_t)out_n);
+    HIPCHK(hipGetLastError());
+    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(out, dout.p, out_n * 8, hipMemcpyDeviceToHost));
+    else HIPCHK(hipDeviceSynchronize());
+    return QD_OK;
+}
+
+int qd_fft_norm_batch(const qd_c32 *in, size_t W, size_t n_fft, size_t in_stride, float *norms, int mem) {
+    if (n_fft == 0) return QD_OK;
+    if (!in || !norms) return fail(QD_ERR_INVALID, "NULL buffer");
+    if (in_stride == 0) return fail(QD_ERR_INVALID, "in_stride 0");
+    qd_chain_desc d{};
+    d.struct_size = sizeof d;
+    d.format = QD_FMT_CF32; d.sample_rate = 1;
+    d.n_samples = (n_fft - 1) * in_stride + W + 1;     // so that the strict `<` loop yields n_fft windows
+    d.width = W; d.stride = in_stride; d.epilogue = QD_EPI_NORMS_F32;
+    // the window loop `i < len - W` needs len - W > (n_fft-1)*stride: len = (n_fft-1)*stride + W + 1
+    qd_plan *p = nullptr;
+    int rc = qd_plan_create(&d, &p);
+    if (rc) return rc;
+    uint64_t have = (n_fft - 1) * in_stride + W;
+    rc = qd_plan_run(p, in, mem, 0, have, 0, n_fft, norms, mem, nullptr);
+    if (rc == QD_OK && mem == QD_MEM_DEVICE) { if (hipDeviceSynchronize() != hipSuccess) rc = fail(QD_ERR_HIP, "sync failed"); }
+    qd_plan_destroy(p);
+    return rc;
+}
+
+int qd_gen(const int64_t *cos_hz, size_t n_cos, uint64_t sample_rate, uint64_t first, size_t n, qd_c32 *out, int mem) {
+    if (!cos_hz || n_cos == 0) return fail(QD_ERR_INVALID, "cos cannot be empty (src/gen.rs:18)");
+    if (sample_rate == 0) return fail(QD_ERR_INVALID, "sample rate may not be zero (src/gen.rs:19)");
+    if (n == 0) return QD_OK;
+    if (!out) return fail(QD_ERR_INVALID, "NULL buffer");
+    DevBuf dc, dout;
+    HIPCHK(hipMalloc(&dc.p, n_cos * 8));
+    HIPCHK(hipMemcpy(dc.p, cos_hz, n_cos * 8, hipMemcpyHostToDevice));
+    float2 *o = reinterpret_cast<float2 *>(out);
+    if (mem == QD_MEM_HOST) { HIPCHK(hipMalloc(&dout.p, n * 8)); o = static_cast<float2 *>(dout.p); }
+    size_t blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_gen, dim3((uint32_t)blocks), dim3(256), 0, 0, static_cast<const int64_t *>(dc.p), (uint32_t)n_cos, sample_rate, first, n, o);
+    HIPCHK(hipGetLastError());
+    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+    else HIPCHK(hipDeviceSynchronize());
+    return QD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Python view of the C ABI (tests / bench plumbing; the compute is in libquadrs_hip.so).
+
+Host numpy arrays go through the QD_MEM_HOST paths; torch CUDA tensors are passed by address
+(QD_MEM_DEVICE) on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import MEM_DEVICE, MEM_HOST, check, lib
+
+_FMT_BYTES = {0: 8, 1: 2, 2: 2, 3: 4}
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def shift_ratio(frequency, sample_rate):
+    """Shift::new's ratio (src/shift.rs:28)."""
+    return lib().qd_shift_ratio(int(frequency), int(sample_rate))
+
+
+def lowpass_design(frequency, sample_rate, size):
+    """lowpass_filter(cutoff, size) (src/filter.rs:86-105)."""
+    out = np.zeros(size, dtype=np.float32)
+    check(lib().qd_lowpass_design(int(frequency), int(sample_rate), size, _np_ptr(out)))
+    return out
+
+
+def unpack(fmt, data):
+    """FileFormat::to_cf32 over a block (src/lib.rs:231-255) on the GPU; returns float32 (n,2)."""
+    data = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+    n = data.size // _FMT_BYTES[fmt]
+    out = np.zeros((n, 2), dtype=np.float32)
+    check(lib().qd_unpack(fmt, _np_ptr(data), n, _np_ptr(out), MEM_HOST))
+    return out
+
+
+def shift(x, abs_off, ratio):
+    """Shift::read_at's loop (src/shift.rs:48-52) on float32 (n,2); returns a new array."""
+    out = np.array(x, dtype=np.float32, copy=True).reshape(-1, 2)
+    check(lib().qd_shift(_np_ptr(out), out.shape[0], int(abs_off), float(ratio), MEM_HOST))
+    return out
+
+
+def lowpass_block(taps, D, raw, valid=None, out_cap=None):
+    """LowPass::read_at on a fetched block (src/filter.rs:68-83)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32).reshape(-1, 2)
+    taps = np.ascontiguousarray(taps, dtype=np.float32)
+    valid = raw.shape[0] if valid is None else valid
+    T = taps.size
+    if out_cap is None:
+        out_cap = max((valid - T) // D, 0) if valid >= T else 0
+    out = np.zeros((max(out_cap, 1), 2), dtype=np.float32)
+    produced = C.c_size_t(0)
+    check(lib().qd_lowpass_block(_np_ptr(taps), T, int(D), _np_ptr(raw), valid, _np_ptr(out), out_cap,
+                                 C.byref(produced), MEM_HOST))
+    return produced.value, out[:out_cap]
+
+
+def fft_norm_batch(x, W, n_fft, in_stride):
+    """Radix4 forward FFT + fftshift + norm per window (src/fft.rs:25,32,48-53)."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((n_fft, W), dtype=np.float32)
+    check(lib().qd_fft_norm_batch(_np_ptr(x), W, n_fft, in_stride, _np_ptr(out), MEM_HOST))
+    return out
+
+
+def gen(cos_hz, sample_rate, first, n):
+    """Gen::read_at (src/gen.rs:35-47) on the GPU; returns float32 (n,2)."""
+    cos = np.ascontiguousarray(cos_hz, dtype=np.int64)
+    out = np.zeros((n, 2), dtype=np.float32)
+    check(lib().qd_gen(_np_ptr(cos), cos.size, int(sample_rate), int(first), n, _np_ptr(out), MEM_HOST))
+    return out
+
+
+class Plan:
+    """The fused chain  from -> [shift] -> [lowpass] -> sparkfft|bucket  (Operation::exec, src/lib.rs:83-175)."""
+
+    def __init__(self, fmt, sample_rate, n_samples, shift_hz=None, lowpass=None, width=128, stride=None,
+                 epilogue=_ffi.EPI_NORMS_F32, rng=None):
+        d = _ffi.ChainDesc()
+        d.struct_size = C.sizeof(_ffi.ChainDesc)
+        d.format = fmt
+        d.sample_rate = sample_rate
+        d.n_samples = n_samples
+        if shift_hz is not None:
+            d.has_shift, d.shift_hz = 1, int(shift_hz)
+        if lowpass is not None:
+            freq, decimate, size = lowpass          # (frequency, -decimate [8], size = 2*-power [40])
+            d.has_lowpass, d.lowpass_hz, d.decimate, d.taps = 1, int(freq), int(decimate), int(size)
+        d.width = width
+        d.stride = width if stride is None else stride
+        d.epilogue = epilogue
+        if rng is not None:
+            d.has_range, d.range_min, d.range_max = 1, rng[0], rng[1]
+        self.desc = d
+        self._h = C.c_void_p()
+        check(lib().qd_plan_create(C.byref(d), C.byref(self._h)))
+        info = _ffi.PlanInfo()
+        check(lib().qd_plan_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.n_windows = info.n_windows
+        self.width = width
+        self.epilogue = epilogue
+
+    def close(self):
+        if self._h:
+            lib().qd_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def taps(self):
+        out = np.zeros(int(self.desc.taps) if self.desc.has_lowpass else 0, dtype=np.float32)
+        if out.size:
+            check(lib().qd_plan_get_taps(self._h, _np_ptr(out), out.size))
+        return out
+
+    def src_range(self, first_window, n_windows):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().qd_plan_src_range(self._h, first_window, n_windows, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def _out_shape_dtype(self, n_windows):
+        if self.epilogue == _ffi.EPI_NORMS_F32:
+            return (n_windows, self.width), np.float32
+        if self.epilogue == _ffi.EPI_GLYPH_U8:
+            return (n_windows, self.width), np.uint8
+        return (n_windows,), np.uint8
+
+    def run_host(self, data, first_window=0, n_windows=None, src_first=0):
+        """data: bytes / uint8 array holding source samples [src_first, ...).  Returns a numpy array."""
+        buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1))
+        n_windows = self.n_windows - first_window if n_windows is None else n_windows
+        shape, dt = self._out_shape_dtype(n_windows)
+        out = np.zeros(shape, dtype=dt)
+        count = buf.size // _FMT_BYTES[self.desc.format]
+        if n_windows:
+            check(lib().qd_plan_run(self._h, _np_ptr(buf), MEM_HOST, src_first, count, first_window, n_windows,
+                                    _np_ptr(out), MEM_HOST, None))
+        return out
+
+    def run_device(self, src, out, first_window=0, n_windows=None, src_first=0, src_count=None, stream=None):
+        """src/out: torch CUDA tensors (any dtype, contiguous).  Enqueues on torch's current stream."""
+        n_windows = self.n_windows - first_window if n_windows is None else n_windows
+        if src_count is None:
+            src_count = src.numel() * src.element_size() // _FMT_BYTES[self.desc.format]
+        st = _cur_stream() if stream is None else C.c_void_p(stream)
+        check(lib().qd_plan_run(self._h, C.c_void_p(src.data_ptr()), MEM_DEVICE, src_first, src_count, first_window,
+                                n_windows, C.c_void_p(out.data_ptr()), MEM_DEVICE, st))
+
+    def set_timing(self, on=True):
+        check(lib().qd_plan_set_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        check(lib().qd_plan_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
