@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def cupboard():
+    with open(os.path.join(GOLDEN, "cupboard-superdec.sr400.cf32"), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def fsk():
+    with open(os.path.join(GOLDEN, "fsk-example-head65536.sr21M.cf32"), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """The HIP engine; building is part of the fixture so a stale .so never passes silently."""
+    from quadrs_amd import build as B
+    B.build()
+    import quadrs_amd
+    return quadrs_amd

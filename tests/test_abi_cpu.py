@@ -1,0 +1,80 @@
+"""CPU tests of the C-ABI library: it loads, exports every declared symbol, and its host-side
+arithmetic (no GPU needed) agrees with the oracle.  No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import bits_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported(engine):
+    from quadrs_amd import _ffi
+    hdr = open(os.path.join(ROOT, "include", "quadrs_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(qd_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    L = C.CDLL(_ffi.LIB_PATH)
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, f"declared in include/quadrs_hip.h but not exported: {missing}"
+    assert sorted(_ffi.SYMBOLS) == declared       # the Python binding covers the whole header
+
+
+def test_struct_layout(engine):
+    from quadrs_amd import _ffi
+    assert C.sizeof(_ffi.ChainDesc) == 104 and C.sizeof(_ffi.PlanInfo) == 72
+
+
+def test_host_arithmetic_matches_oracle(engine, oracle):
+    L = engine._ffi.lib()
+    for fmt in range(4):
+        assert L.qd_pair_bytes(fmt) == oracle.lib().qo_pair_bytes(fmt)
+    for f, sr in ((280000, 21_000_000), (-280000, 21_000_000), (1, 3), (12_345_678, 100_000_000)):
+        assert engine.shift_ratio(f, sr) == oracle.shift_ratio(f, sr)
+    for T, fc, sr in ((40, 2_000_000, 21_000_000), (400, 200_000, 21_000_000), (512, 5_000_000, 100_000_000), (2, 1, 7)):
+        assert bits_equal(engine.lowpass_design(fc, sr, T), oracle.taps(fc, sr, T))
+    # odd size: sinc(0) = NaN at the centre tap, as in the reference
+    a, b = engine.lowpass_design(1000, 48000, 5), oracle.taps(1000, 48000, 5)
+    assert np.isnan(a).all() and np.isnan(b).all()     # NaN sum poisons every tap after normalisation
+
+
+@pytest.mark.parametrize("kwargs,code", [
+    (dict(width=100), 2),                                   # Radix4 needs a power of two -> panic
+    (dict(width=128, stride=0), 1),                         # never terminates -> invalid
+    (dict(width=128, shift_hz=10_500_000), 2),              # |f| < sr/2 (src/shift.rs:20-23)
+    (dict(width=128, lowpass=(1000, 0, 40)), 2),            # decimate 0
+    (dict(width=128, lowpass=(1000, 8, 1)), 2),             # size < 2
+    (dict(width=4096, n_samples=100), 2),                   # len < width underflow (src/fft.rs:28)
+    (dict(width=128, lowpass=(1000, 8, 40), n_samples=30), 2),   # inner.len() < filter.len()
+])
+def test_plan_validation_precedes_any_gpu_call(engine, kwargs, code):
+    """Argument checks mirror the reference's asserts and run before the first HIP call."""
+    kw = dict(fmt=engine.FMT_CF32, sample_rate=21_000_000, n_samples=1 << 20)
+    kw.update(kwargs)
+    with pytest.raises(engine.QuadrsError) as ei:
+        engine.Plan(**kw)
+    assert ei.value.code == code
+
+
+def test_missing_library_fails_loudly(engine, monkeypatch):
+    from quadrs_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", "/nonexistent/libquadrs_hip.so")
+    with pytest.raises(ImportError):
+        _ffi.lib()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under quadrs_amd/ or include/ may reference it."""
+    bad = []
+    for d in ("quadrs_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c")):
+                    txt = open(os.path.join(dirpath, f), errors="replace").read()
+                    if re.search(r"quadrs_oracle|from oracle|import oracle|qo_[a-z]", txt):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -1,0 +1,362 @@
+"""GPU parity tests (-m gpu): every call goes through the C ABI (ctypes) into the HIP kernels and
+is compared with the CPU oracle on the same inputs.
+
+Tolerances (written here once):
+  * integer unpack, FIR+decimate, FFT, hypot, glyph/bucket: bit-exact against the oracle.
+  * shift (NCO): the f32 multiplier is the f32 rounding of an f64 cos/sin whose absolute error on
+    the GPU is ~4e-16, so it equals glibc's except when the f64 value sits within that distance of
+    an f32 rounding boundary (p ~ 1e-8) or the component itself is ~0 (zero crossings).  The cf32
+    output is required to be within 1 ulp of the sample's magnitude (`complex_ulp_err <= 1`) and
+    bit-exact for >= 99.9 % of samples.
+  * fused chain norms: bit-exact for >= 99.9 % of bins, never further than 4 ulp of the window's
+    largest norm (an NCO 1-ulp event propagates through 40-400 taps and a W-point FFT).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import README_OOK, bits_equal, complex_ulp_err, ook_pipeline, ulp_diff, ulp_of
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+
+
+def assert_norms_close(ref, got, what=""):
+    assert ref.shape == got.shape, (ref.shape, got.shape)
+    exact = (ref.view(np.uint32) == got.view(np.uint32))
+    frac = exact.mean() if exact.size else 1.0
+    scale = ulp_of(ref.max(axis=-1, keepdims=True)).astype(np.float64)
+    worst = (np.abs(ref.astype(np.float64) - got.astype(np.float64)) / scale).max() if ref.size else 0.0
+    assert frac >= 0.999 and worst <= 4.0, f"{what}: bit-exact fraction {frac:.6f}, worst {worst:.2f} ulp(window max)"
+
+
+# ------------------------------------------------------------------ A1 unpack
+
+def test_unpack_exhaustive_bit_exact(engine, oracle, vec):
+    b = np.arange(256, dtype=np.uint8)
+    pairs8 = np.stack([b, b[::-1]], axis=1).reshape(-1).tobytes()
+    for fmt, key in ((engine.FMT_CS8, "unpack_cs8"), (engine.FMT_CU8, "unpack_cu8")):
+        got = engine.unpack(fmt, pairs8)
+        assert bits_equal(got, vec[key]) and bits_equal(got, oracle.unpack(fmt, pairs8))
+    h = np.arange(65536, dtype=np.uint16)
+    pairs16 = np.stack([h, h[::-1]], axis=1).reshape(-1).astype("<u2").tobytes()
+    got = engine.unpack(engine.FMT_CS16, pairs16)
+    assert bits_equal(got, oracle.unpack(oracle.FMT_CS16, pairs16))
+    assert bits_equal(got[::257], vec["unpack_cs16_every257"])
+    raw = np.array([0x7FC00001, 0xFF800000, 0x00000001, 0x80000000], dtype="<u4").tobytes()
+    assert engine.unpack(engine.FMT_CF32, raw).view(np.uint32).tolist() == [[0x7FC00001, 0xFF800000], [1, 0x80000000]]
+    assert engine.unpack(engine.FMT_CS8, b"").shape == (0, 2)            # empty input
+
+
+# ------------------------------------------------------------------ A3 shift
+
+@pytest.mark.parametrize("freq,sr", [(280000, 21_000_000), (-1_234_567, 21_000_000), (3, 400), (49_999_999, 100_000_000)])
+def test_shift_block_within_one_ulp(engine, oracle, freq, sr):
+    rng = np.random.default_rng(freq & 0xFFFF)
+    x = (rng.standard_normal((50_000, 2)) * 0.03).astype(np.float32)
+    ratio = engine.shift_ratio(freq, sr)
+    for off in (0, 1, 511, 987_654_321, 2**31 - 5, 2**33 + 12_345, 2**34 - 50_000):
+        ref = oracle.shift_apply(x, off, ratio)
+        got = engine.shift(x, off, ratio)
+        err = complex_ulp_err(ref, got)
+        exact = (ref.view(np.uint32) == got.view(np.uint32)).all(axis=1).mean()
+        assert err.max() <= 1.0 and exact >= 0.999, (off, err.max(), exact)
+
+
+def test_shift_multipliers_against_golden(engine, vec):
+    """x = 1+0i makes the output the multiplier itself (re = 1*c - 0*s, im = 1*s + 0*c)."""
+    ratio = float(vec["nco_ratio"][0])
+    one = np.array([[1.0, 0.0]], dtype=np.float32)
+    for n, want in zip(vec["nco_n"], vec["nco_mul"]):
+        got = engine.shift(one, int(n), ratio)[0]
+        for comp in (0, 1):
+            if abs(want[comp]) > 1e-6:
+                assert got[comp] == want[comp], (int(n), comp, got, want)
+            else:                                   # zero crossing: absolute accuracy ~4e-16 only
+                assert abs(float(got[comp]) - float(want[comp])) < 1e-15
+
+
+def test_shift_edge_cases(engine, oracle):
+    x = np.array([[1.0, -2.0], [np.inf, 0.0], [np.nan, 1.0], [0.0, -0.0], [1e-45, 3e38]], dtype=np.float32)
+    ratio = engine.shift_ratio(1000, 48000)
+    ref, got = oracle.shift_apply(x, 7, ratio), engine.shift(x, 7, ratio)
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    m = ~np.isnan(ref)
+    assert bits_equal(ref[m], got[m])
+    assert engine.shift(np.zeros((0, 2), np.float32), 0, ratio).shape == (0, 2)
+    assert bits_equal(engine.shift(x[:1], 5, 0.0), x[:1])                 # ratio 0: multiplier (1, 0)
+
+
+# ------------------------------------------------------------------ A5 FIR + decimate
+
+@pytest.mark.parametrize("T,D,B", [(40, 16, 128), (400, 32, 64), (512, 8, 70), (40, 8, 4096), (10, 7, 33), (6, 1, 50),
+                                    (2, 3, 9), (64, 64, 5), (30, 100, 7)])
+def test_lowpass_block_bit_exact(engine, oracle, T, D, B):
+    rng = np.random.default_rng(T * 1000 + D)
+    raw = rng.standard_normal((B * D + T, 2)).astype(np.float32)
+    taps = oracle.taps(1000, 16000, T)
+    n_ref, ref = oracle.lowpass_block(taps, D, raw)
+    n_got, got = engine.lowpass_block(taps, D, raw)
+    assert n_ref == n_got == B and bits_equal(ref, got)
+    # short read (EOF): fewer valid samples => fewer outputs, deeper truncation
+    valid = raw.shape[0] - (D // 2 + 3)
+    if valid >= T:
+        n_ref, ref = oracle.lowpass_block(taps, D, raw, valid=valid)
+        n_got, got = engine.lowpass_block(taps, D, raw, valid=valid)
+        assert n_ref == n_got and bits_equal(ref[:n_ref], got[:n_got])
+
+
+def test_lowpass_block_panics_like_the_reference(engine):
+    taps = np.ones(8, dtype=np.float32)
+    with pytest.raises(engine.QuadrsError) as ei:
+        engine.lowpass_block(taps, 2, np.zeros((5, 2), np.float32))       # valid < T
+    assert ei.value.code == 2
+    with pytest.raises(engine.QuadrsError) as ei:
+        engine.lowpass_block(taps, 2, np.zeros((40, 2), np.float32), out_cap=3)   # buf too small
+    assert ei.value.code == 2
+
+
+# ------------------------------------------------------------------ A6 FFT + norm
+
+@pytest.mark.parametrize("W", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_fft_norm_batch_bit_exact(engine, oracle, W):
+    rng = np.random.default_rng(W)
+    n_fft, stride = 5, max(1, W // 2 + 1)
+    x = rng.standard_normal(((n_fft - 1) * stride + W, 2)).astype(np.float32)
+    got = engine.fft_norm_batch(x, W, n_fft, stride)
+    for i in range(n_fft):
+        y = oracle.fft(x[i * stride:i * stride + W])
+        ref = oracle.norm(y)[np.r_[W // 2:W, 0:W // 2]] if W > 1 else oracle.norm(y)
+        assert bits_equal(ref, got[i]), (W, i)
+
+
+def test_fft_golden_and_f64_truth(engine, oracle, vec):
+    for W in (4, 64, 128, 1024):
+        xin = vec[f"fft_in_{W}"]
+        got = engine.fft_norm_batch(xin, W, 1, W)[0]
+        want = oracle.norm(vec[f"fft_out_{W}"])[np.r_[W // 2:W, 0:W // 2]]
+        assert bits_equal(got, want)
+        truth = np.abs(oracle.dft_f64(xin))[np.r_[W // 2:W, 0:W // 2]]
+        # rustfft's internal rounding is unpinned: bound the result against the f64 DFT
+        assert np.abs(got - truth).max() <= 8 * np.log2(W) * np.finfo(np.float32).eps * truth.max()
+
+
+def test_norm_special_values(engine, oracle):
+    x = np.array([[3.0, 4.0], [np.inf, np.nan], [np.nan, 1.0], [1e-45, 0.0], [3e38, 3e38], [-0.0, 0.0]], dtype=np.float32)
+    got = engine.fft_norm_batch(x, 1, x.shape[0], 1)[:, 0]
+    ref = oracle.norm(x)
+    assert np.array_equal(np.isnan(ref), np.isnan(got)) and bits_equal(ref[~np.isnan(ref)], got[~np.isnan(got)])
+
+
+# ------------------------------------------------------------------ fused chain
+
+def test_cfg1_readme_known_answer_on_gpu(engine, oracle, cupboard):
+    """configs[0] + README.md:113-116,167 through the HIP path, rendered by the host."""
+    n = len(cupboard) // 8
+    p = engine.Plan(engine.FMT_CF32, 400, n, width=4, stride=2, epilogue=engine.EPI_GLYPH_U8, rng=(0.001, 0.01))
+    assert p.n_windows == 995
+    codes = p.run_host(cupboard)
+    text = oracle.render(400, codes)
+    assert ook_pipeline(text) == README_OOK
+    ref_norms, ref_codes = oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400).spark_fft(4, 2, (0.001, 0.01))
+    assert np.array_equal(codes, ref_codes)
+    pn = engine.Plan(engine.FMT_CF32, 400, n, width=4, stride=2)
+    assert bits_equal(pn.run_host(cupboard), ref_norms)
+    blank = engine.Plan(engine.FMT_CF32, 400, n, width=4, stride=2, epilogue=engine.EPI_GLYPH_U8).run_host(cupboard)
+    assert not blank.any()                                    # default range 0.08..1.0 (src/fft.rs:22-23)
+
+
+def test_fsk_readme_chain_against_golden(engine, oracle, fsk, vec):
+    """README.md:90-94: shift 280000 | lowpass -power 200 -decimate 32 200000 | sparkfft -width 64 -stride 16."""
+    p = engine.Plan(engine.FMT_CF32, 21_000_000, len(fsk) // 8, shift_hz=280000, lowpass=(200000, 32, 400),
+                    width=64, stride=16)
+    assert p.n_windows == int(vec["fsk_nwin"][0]) and p.info.out_sample_rate == 656250
+    assert bits_equal(p.taps(), oracle.taps(200000, 21_000_000, 400))
+    got = p.run_host(fsk)
+    assert_norms_close(vec["fsk_norms_first64"], got[:64], "fsk first64")
+    assert_norms_close(vec["fsk_norms_last16"], got[-16:], "fsk last16")
+    assert set(np.unique(got.argmax(axis=1)[:32])) <= {23, 24, 25, 47, 48, 49}
+
+
+def _signal(rng, n, amp=0.02):
+    t = np.arange(n)
+    z = amp * np.exp(2j * np.pi * (-0.0133) * t) * np.sign(np.sin(2 * np.pi * t / 2187.0) + 1e-9)
+    z = z + 0.002 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) + (0.005 - 0.024j)
+    return np.stack([z.real, z.imag], axis=1).astype(np.float32)
+
+
+def _to_format(x, fmt):
+    if fmt == 0:
+        return x.tobytes()
+    if fmt == 1:
+        return np.clip(np.round(x * 127 * 20), -128, 127).astype(np.int8).tobytes()
+    if fmt == 2:
+        return np.clip(np.round(x * 127 * 20 + 127.5), 0, 255).astype(np.uint8).tobytes()
+    return np.clip(np.round(x * 32767 * 20), -32768, 32767).astype("<i2").tobytes()
+
+
+CHAINS = [
+    # fmt, N, shift, (fc, D, T), W, S
+    (0, 300_000, 280000, (2_000_000, 16, 40), 128, 128),      # cfg 2 shape
+    (1, 200_000, 280000, (200_000, 32, 400), 64, 16),         # cfg 3 shape (cs8, overlapping windows)
+    (0, 400_000, 280000, (200_000, 32, 200), 128, 128),       # cfg 3' shape
+    (0, 150_000, 1_000_000, (5_000_000, 8, 512), 1024, 1024), # cfg 4 shape
+    (2, 100_000, -500_000, (1_000_000, 8, 40), 32, 8),        # cu8, negative shift
+    (3, 100_000, 123_456, (700_000, 10, 24), 16, 5),          # cs16, D not a power of two
+    (0, 60_000, None, (2_000_000, 16, 40), 128, 64),          # no shift
+    (0, 20_000, 280000, None, 64, 7),                         # no lowpass
+    (1, 9_000, None, None, 8, 8),                             # from -> sparkfft only
+    (0, 50_000, 5_000, (300_000, 3, 10), 4, 1),               # odd D, stride 1
+    (0, 30_000, 280000, (2_000_000, 1, 6), 256, 256),         # decimate 1
+    (0, 70_000, 280000, (2_000_000, 64, 30), 8, 2),           # T/2 < D: no truncated outputs
+]
+
+
+@pytest.mark.parametrize("fmt,N,shift,lp,W,S", CHAINS)
+def test_fused_chain_matches_oracle(engine, oracle, fmt, N, shift, lp, W, S):
+    rng = np.random.default_rng(N + W)
+    data = _to_format(_signal(rng, N), fmt)
+    sr = 21_000_000
+    ch = oracle.Chain.from_bytes(data, fmt, sr)
+    if shift is not None:
+        ch = ch.shift(shift)
+    if lp is not None:
+        ch = ch.lowpass(lp[0], lp[1], lp[2])
+    p = engine.Plan(fmt, sr, N, shift_hz=shift, lowpass=lp, width=W, stride=S)
+    assert p.info.decimated_len == ch.len() and p.info.out_sample_rate == ch.sample_rate()
+    ref, _ = ch.spark_fft(W, S, max_windows=400)
+    assert p.n_windows == oracle.lib().qo_spark_window_count(ch.len(), W, S)
+    got = p.run_host(data, 0, ref.shape[0])
+    assert_norms_close(ref, got, f"chain fmt={fmt} W={W} S={S}")
+    # the tail of the stream (last windows touch the last admissible samples)
+    tail0 = max(0, p.n_windows - 37)
+    ref_t, _ = ch.spark_fft(W, S, first_window=tail0)
+    got_t = p.run_host(data, tail0, p.n_windows - tail0)
+    assert_norms_close(ref_t, got_t, "tail")
+
+
+def test_glyph_and_bucket_epilogues(engine, oracle, fsk):
+    n = 40_000
+    data = fsk[: n * 8]
+    ch = oracle.Chain.from_bytes(data, 0, 21_000_000).shift(280000).lowpass(2_000_000, 16, 40)
+    ref_norms, ref_codes = ch.spark_fft(32, 8, (0.01, 0.3))
+    p = engine.Plan(0, 21_000_000, n, shift_hz=280000, lowpass=(2_000_000, 16, 40), width=32, stride=8,
+                    epilogue=engine.EPI_GLYPH_U8, rng=(0.01, 0.3))
+    codes = p.run_host(data)
+    assert codes.shape == ref_codes.shape and (codes == ref_codes).mean() >= 0.9995
+    assert len(np.unique(ref_codes)) >= 5                      # the range really exercises the glyph ladder
+    pb = engine.Plan(0, 21_000_000, n, shift_hz=280000, lowpass=(2_000_000, 16, 40), width=32, stride=8,
+                     epilogue=engine.EPI_BUCKET2_U8)
+    vals = pb.run_host(data)
+    ref_vals = ch.freq_levels(32, 8)
+    assert pb.n_windows == ref_vals.size == (ch.len() - 32) // 8   # floor count, not the strict-< loop
+    assert (vals == ref_vals).mean() >= 0.9995 and 0 < ref_vals.mean() < 1
+
+
+def test_window_subranges_and_slabs_concatenate(engine, oracle):
+    """§8(e): windows are independent; a slab [src_first, ...) + absolute indices reproduces the
+    whole-stream run bit for bit — including seams and an unaligned (odd) slab start."""
+    rng = np.random.default_rng(5)
+    N = 600_000
+    x = _signal(rng, N)
+    data = x.tobytes()
+    p = engine.Plan(0, 21_000_000, N, shift_hz=280000, lowpass=(200_000, 32, 400), width=64, stride=16)
+    whole = p.run_host(data)
+    for shards in (2, 3, 8):
+        bounds = np.linspace(0, p.n_windows, shards + 1).astype(np.int64)
+        parts = []
+        for g in range(shards):
+            w0, w1 = int(bounds[g]), int(bounds[g + 1])
+            first, count = p.src_range(w0, w1 - w0)
+            assert count == (w1 - w0 - 1) * 16 * 32 + 64 * 32 + 400            # halo (W-S)*D + T past the last step
+            slab = x[first:first + count].tobytes()
+            parts.append(p.run_host(slab, w0, w1 - w0, src_first=first))
+        assert bits_equal(np.concatenate(parts), whole), shards
+    # odd slab start forces the scalar-load path
+    first, count = p.src_range(11, 50)
+    a = p.run_host(x[first - 1:first + count].tobytes(), 11, 50, src_first=first - 1)
+    assert bits_equal(a, whole[11:61])
+    with pytest.raises(engine.QuadrsError):
+        p.run_host(x[first + 1:first + count].tobytes(), 11, 50, src_first=first + 1)   # slab misses a sample
+    with pytest.raises(engine.QuadrsError):
+        p.run_host(data, p.n_windows - 1, 2)                                            # past the sink's loop
+
+
+def test_device_resident_run_equals_host_run(engine):
+    import torch
+    rng = np.random.default_rng(9)
+    N = 1_000_000
+    x = _signal(rng, N)
+    p = engine.Plan(0, 21_000_000, N, shift_hz=280000, lowpass=(2_000_000, 16, 40), width=128)
+    host = p.run_host(x.tobytes())
+    src = torch.from_numpy(x).cuda()
+    out = torch.empty(p.n_windows, 128, device="cuda", dtype=torch.float32)
+    p.set_timing(True)
+    p.run_device(src, out)
+    torch.cuda.synchronize()
+    assert p.last_kernel_ms() > 0
+    assert bits_equal(out.cpu().numpy(), host)
+    # idempotent
+    out2 = torch.empty_like(out)
+    p.run_device(src, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_gen_against_golden(engine, vec):
+    tones = vec["gen_tones"]
+    a = engine.gen(tones, 100_000_000, 0, 64)
+    b = engine.gen(tones, 100_000_000, 2**32 - 64, 64)
+    # 64 f32-rounded terms per sample; a 1-ulp multiplier event (p~1e-8 each) would show as <= 1 ulp
+    assert complex_ulp_err(vec["gen_first64"], a).max() <= 1.0 and complex_ulp_err(vec["gen_far64"], b).max() <= 1.0
+    assert (a.view(np.uint32) == vec["gen_first64"].view(np.uint32)).mean() >= 0.99
+
+
+def test_cfg2_full_size_properties(engine, oracle):
+    """BASELINE configs[1] at full size (1 GiB cf32): oracle on a window subsample + size-independent
+    properties: exact linearity under x2 scaling, idempotence, and shard concatenation."""
+    import torch
+    N = 1 << 27
+    torch.manual_seed(2)
+    src = torch.randn(N, 2, device="cuda", dtype=torch.float32) * 0.02
+    p = engine.Plan(0, 21_000_000, N, shift_hz=280000, lowpass=(2_000_000, 16, 40), width=128)
+    assert p.n_windows == 65535 and p.info.decimated_len == 8388606           # SURVEY §8 cfg 2 row
+    out = torch.empty(p.n_windows, 128, device="cuda", dtype=torch.float32)
+    p.run_device(src, out)
+    torch.cuda.synchronize()
+    host_out = out.cpu().numpy()
+    rng = np.random.default_rng(0)
+    picks = sorted(set([0, 1, 2, 65532, 65533, 65534] + rng.integers(0, 65535, 40).tolist()))
+    for w in picks:
+        first, count = p.src_range(w, 1)
+        slab = src[first:first + count].cpu().numpy()
+        ch = oracle.Chain.from_bytes(np.concatenate([slab, np.zeros((130, 2), np.float32)]).tobytes(), 0, 21_000_000)
+        # absolute phase: apply the oracle's shift at the absolute offset, then lowpass + fft
+        shifted = oracle.shift_apply(slab, first, oracle.shift_ratio(280000, 21_000_000))
+        n_out, dec = oracle.lowpass_block(oracle.taps(2_000_000, 21_000_000, 40), 16, shifted)
+        assert n_out == 128
+        ref = oracle.norm(oracle.fft(dec))[np.r_[64:128, 0:64]]
+        assert_norms_close(ref[None], host_out[w][None], f"cfg2 window {w}")
+        del ch
+    # linearity: doubling the input doubles every norm exactly (power-of-two scaling is exact)
+    src2 = src * 2
+    out2 = torch.empty_like(out)
+    p.run_device(src2, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out * 2)
+    del src2
+    # two shards with halo == whole
+    half = p.n_windows // 2
+    for w0, w1 in ((0, half), (half, p.n_windows)):
+        first, count = p.src_range(w0, w1 - w0)
+        part = torch.empty(w1 - w0, 128, device="cuda", dtype=torch.float32)
+        p.run_device(src[first:first + count], part, w0, w1 - w0, src_first=first, src_count=count)
+        torch.cuda.synchronize()
+        assert torch.equal(part, out[w0:w1])

@@ -1,0 +1,194 @@
+"""CPU tests: the oracle against the reference's only known-answers and against the pinned vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from util import README_OOK, bits_equal, ook_pipeline
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+
+
+def test_readme_ook_string(oracle, cupboard):
+    """README.md:113-116 + :167 — the one externally authored known-answer on the hot path."""
+    ch = oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400)
+    assert ch.len() == 1994
+    text = ch.spark_text(4, 2, (0.001, 0.01))
+    lines = text.decode().split("\n")
+    assert lines[0] == "sparkfft sample_rate=400"          # src/fft.rs:19
+    assert len(lines) == 1 + 995 + 1                       # strict `<` loop: 995 windows (SURVEY §8 cfg 1)
+    assert ook_pipeline(text) == README_OOK
+
+
+def test_readme_ook_decodes_to_24_6_degrees(oracle, cupboard):
+    """README.md:181-187: bytes 00011000 (24) and 10011001 (153)."""
+    import re
+    ab = ook_pipeline(oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400).spark_text(4, 2, (0.001, 0.01)))
+    pairs = re.sub(r".*BBBBABAB(AB)*BABA", "", ab)
+    pairs = re.sub(r"(..)", r"\1_", pairs)
+    bits = pairs.replace("AB_", "0").replace("BA_", "1")
+    assert bits.startswith("00011000" + "0" + "10011001")
+
+
+def test_default_range_blanks_cfg1(oracle, cupboard):
+    """configs[0] as written has no -range: min 0.08 / max 1.0 (src/fft.rs:22-23) => all blank."""
+    _, codes = oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400).spark_fft(4, 2)
+    assert codes.shape == (995, 4) and not codes.any()
+
+
+def test_fsk_chain_tones(oracle, fsk, vec):
+    """README.md:90-94: the two FSK tones sit at columns 24 and 48 of 64 (screenshots/fsk-5.png)."""
+    ch = oracle.Chain.from_bytes(fsk, oracle.FMT_CF32, 21_000_000).shift(280000).lowpass(200000, 32, 400)
+    assert ch.sample_rate() == 656250
+    norms, _ = ch.spark_fft(64, 16)
+    assert norms.shape[0] == int(vec["fsk_nwin"][0])
+    peaks = norms.argmax(axis=1)
+    assert set(np.unique(peaks[:32])) <= {23, 24, 25, 47, 48, 49}
+    assert bits_equal(norms[:64], vec["fsk_norms_first64"]) and bits_equal(norms[-16:], vec["fsk_norms_last16"])
+
+
+def test_literal_convolve_equals_closed_form(oracle, fsk):
+    """complex_convolve over every position (src/filter.rs:107-124) == kept-outputs-only closed form."""
+    ch = oracle.Chain.from_bytes(fsk[: 8 * 30000], oracle.FMT_CF32, 21_000_000).shift(280000).lowpass(2_000_000, 16, 40)
+    oracle.lib().qo_set_lowpass_closed_form(0)
+    try:
+        a = ch.read_at(3, 200)
+        b8 = ch.spark_fft(128, 128, max_windows=3)[0]
+    finally:
+        oracle.lib().qo_set_lowpass_closed_form(1)
+    b = ch.read_at(3, 200)
+    assert a[0] == b[0] == 200 and bits_equal(a[1], b[1])
+    assert bits_equal(b8, ch.spark_fft(128, 128, max_windows=3)[0])
+
+
+def test_tail_truncation_counts(oracle):
+    """the last ceil((T/2 - D)/D) outputs of every read_at use a prefix of the taps."""
+    rng = np.random.default_rng(3)
+    for T, D, expect in ((40, 16, 1), (400, 32, 6), (512, 8, 31)):
+        B = 64
+        x = rng.standard_normal((B * D + T + 4 * T, 2)).astype(np.float32)
+        taps = oracle.taps(1000, 100000, T)
+        got, blk = oracle.lowpass_block(taps, D, x[: B * D + T])
+        assert got == B
+        # untruncated values: same outputs computed inside a longer read
+        _, full = oracle.lowpass_block(taps, D, x)
+        differs = np.nonzero((blk.view(np.uint32) != full[:B].view(np.uint32)).any(axis=1))[0]
+        assert differs.size <= expect and (differs.size == 0 or differs.min() >= B - expect)
+        assert differs.size >= expect - 1      # random data: essentially always all of them
+
+
+def test_taps_vectors(oracle, vec):
+    for T, fc, sr in ((40, 2_000_000, 21_000_000), (200, 200_000, 21_000_000), (400, 200_000, 21_000_000),
+                      (512, 5_000_000, 100_000_000)):
+        assert bits_equal(oracle.taps(fc, sr, T), vec[f"taps_{T}_{fc}_{sr}"])
+    t = oracle.taps(200_000, 21_000_000, 400)     # SURVEY §8(a) A4 probe values
+    assert abs(t[0] - 1.397e-11) < 1e-13 and abs(t[199] - 0.0190390) < 1e-6 and abs(t.sum() - 1.0) < 1e-6
+
+
+def test_unpack_vectors(oracle, vec):
+    b = np.arange(256, dtype=np.uint8)
+    pairs8 = np.stack([b, b[::-1]], axis=1).reshape(-1).tobytes()
+    cs8 = oracle.unpack(oracle.FMT_CS8, pairs8)
+    cu8 = oracle.unpack(oracle.FMT_CU8, pairs8)
+    assert bits_equal(cs8, vec["unpack_cs8"]) and bits_equal(cu8, vec["unpack_cu8"])
+    # src/lib.rs:251-252 ranges
+    assert cs8.min() == np.float32(-128.0) / np.float32(127.0) and cs8.max() == 1.0
+    assert cu8.min() == -127.5 and cu8.max() == -126.5
+    h = np.arange(65536, dtype=np.uint16)
+    pairs16 = np.stack([h, h[::-1]], axis=1).reshape(-1).astype("<u2").tobytes()
+    full = oracle.unpack(oracle.FMT_CS16, pairs16)
+    assert bits_equal(full[::257], vec["unpack_cs16_every257"])
+    assert np.bitwise_xor.reduce(full.view(np.uint32).reshape(-1)) == vec["unpack_cs16_xor"][0]
+    # cf32 is a bit copy, including NaN payloads
+    raw = np.array([0x7FC00001, 0xFF800000, 0x00000001, 0x80000000], dtype="<u4").tobytes()
+    assert oracle.unpack(oracle.FMT_CF32, raw).view(np.uint32).tolist() == [[0x7FC00001, 0xFF800000], [1, 0x80000000]]
+
+
+def test_nco_vectors(oracle, vec):
+    ratio = oracle.shift_ratio(280000, 21_000_000)
+    assert ratio == vec["nco_ratio"][0]
+    assert bits_equal(oracle.shift_multipliers(ratio, vec["nco_n"]), vec["nco_mul"])
+    # e^{+i theta}: positive frequency turns counter-clockwise (SURVEY §4 probe)
+    m = oracle.shift_multipliers(ratio, [1])[0]
+    assert m[0] > 0 and m[1] > 0
+
+
+def test_gen_vectors(oracle, vec):
+    g = oracle.Chain.gen(vec["gen_tones"], 100_000_000, 42.94967296)
+    assert g.len() == int(vec["gen_len"][0]) == 2**32          # exactly 2^32
+    assert bits_equal(g.read_at(0, 64)[1], vec["gen_first64"])
+    assert bits_equal(g.read_at(2**32 - 64, 64)[1], vec["gen_far64"])
+    with pytest.raises(ValueError):
+        oracle.Chain.gen([], 100, 1.0)                          # src/gen.rs:18
+
+
+def test_write_block_truncation(oracle, vec):
+    """do_write after lowpass (src/lib.rs:199-210): 0x1000-sample blocks, each with its own tail
+    truncation, ending in the assert_ne!(0, read) panic because LowPass::len over-reports by one."""
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((3 * 4096 * 4 + 40 + 100, 2)) * 0.05).astype(np.float32)
+    w = oracle.Chain.from_bytes(x.tobytes(), oracle.FMT_CF32, 1_000_000).lowpass(100_000, 4, 40)
+    rc, n, samples = w.do_write(4 * 4096)
+    assert [rc, n] == vec["write_rc_n"].tolist()
+    assert rc == 2 and n == w.len() - 1
+    assert bits_equal(samples, vec["write_samples"])
+
+
+def test_fft_vectors_and_truth(oracle, vec):
+    for W in (4, 64, 128, 1024):
+        xin = vec[f"fft_in_{W}"]
+        y = oracle.fft(xin)
+        assert bits_equal(y, vec[f"fft_out_{W}"])
+        truth = oracle.dft_f64(xin)
+        err = np.abs((y[:, 0] + 1j * y[:, 1]) - truth).max()
+        # parity unpinned (rustfft source absent): bounded against the f64 DFT instead
+        assert err <= 4 * np.log2(W) * np.finfo(np.float32).eps * np.linalg.norm(truth) / np.sqrt(W) * 4
+
+
+def test_fft_layout_matches_radix4_plan(oracle):
+    """Radix4::new base selection: 1,2,4,8 then odd exponent -> 8, even -> 16."""
+    assert [oracle.fft_twiddles(n)[0] for n in (1, 2, 4, 8, 16, 32, 64, 128, 256, 1024, 4096)] == \
+        [1, 2, 4, 8, 16, 8, 16, 8, 16, 16, 16]
+    base, tw = oracle.fft_twiddles(128)        # 8 -> 32 -> 128: 3*8 + 3*32 twiddles
+    assert tw.shape[0] == 3 * 8 + 3 * 32 and tuple(tw[0]) == (1.0, -0.0)
+
+
+def test_window_counts(oracle):
+    L = oracle.lib()
+    assert L.qo_spark_window_count(1994, 4, 2) == 995
+    assert L.qo_spark_window_count(8388606, 128, 128) == 65535        # cfg 2
+    assert L.qo_spark_window_count(268435444, 64, 16) == 16777212     # cfg 3
+    assert L.qo_spark_window_count(10, 10, 1) == 0
+    assert L.qo_spark_window_count(9, 10, 1) == oracle.U64_MAX         # u64 underflow (src/fft.rs:28)
+
+
+def test_glyph_thresholds(oracle):
+    g = oracle.lib().qo_glyph_code
+    assert g(0.0009, 0.001, 0.01) == 0 and g(0.01, 0.001, 0.01) == 8 and g(0.001, 0.001, 0.01) == 1
+    assert g(float("nan"), 0.001, 0.01) == 1       # NaN: both compares false, `as usize` -> 0
+    assert g(0.0099999, 0.001, 0.01) in (7, 255)
+
+
+def test_bucket_and_take_fft_smoke(oracle, cupboard, fsk):
+    ch = oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400)
+    vals = ch.freq_levels(4, 2)
+    assert vals.size == (1994 - 4) // 2 and set(np.unique(vals)) <= {0, 1}     # floor count (src/fft.rs:86)
+    rc, rows, offs = oracle.Chain.from_bytes(fsk, oracle.FMT_CF32, 21_000_000).take_fft(256, 32)
+    assert rc == 0 and rows.shape == (32, 256) and offs[0] == 0 and np.isfinite(rows).all()
+
+
+def test_panics_and_short_reads(oracle, cupboard):
+    ch = oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400)
+    assert ch.read_at(1994, 4)[0] == oracle.PANIC                      # assert!(off < len), src/samples.rs:74
+    assert ch.read_at(1992, 4)[0] == 2                                  # short read at EOF
+    with pytest.raises(AssertionError):
+        oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400).shift(200)   # |f| < sr/2, src/shift.rs:20
+    lp = oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400).lowpass(50, 8, 40)
+    assert lp.len() == 1 + (1994 - 40) // 8
+    assert lp.read_at(lp.len() - 1, 1)[0] == 0                         # len over-reports by one
+    assert lp.read_at(lp.len(), 1)[0] == oracle.PANIC                  # valid < T underflow, src/filter.rs:76

@@ -1,0 +1,92 @@
+"""world_size-2/3 gloo tests of the multi-rank path on CPU: partition + neighbour halo exchange
+(the same torch.distributed calls bench.py issues over RCCL), checked with the oracle: the
+concatenation of per-rank outputs must equal the single-rank result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, cfg, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from quadrs_amd import shard as SH
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shift, (fc, D, T), W, S = cfg
+    rng = np.random.default_rng(1234)
+    x = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)       # every rank can rebuild the stream
+    dec_len = 1 + (n - T) // D
+    n_windows = O.lib().qo_spark_window_count(dec_len, W, S)
+    shards = SH.partition(n_windows, world, S * D, W * D + T, tile_windows=4)
+    me = shards[rank]
+    own = torch.from_numpy(x[me.own_first:me.own_first + me.own_count].copy()).view(torch.uint8).reshape(-1)
+    full = SH.exchange(own, shards, rank, 8, dist)
+    slab = full.numpy().view(np.float32).reshape(-1, 2)
+    assert slab.shape[0] == me.need_count
+    assert np.array_equal(slab, x[me.need_first:me.need_first + me.need_count])     # halo bytes are right
+    # per-rank result with absolute indices: shift at the absolute offset, then per-window FIR + FFT
+    ratio = O.shift_ratio(shift, 21_000_000)
+    taps = O.taps(fc, 21_000_000, T)
+    rows = []
+    for w in range(me.w0, me.w1):
+        a = w * S * D - me.need_first
+        raw = O.shift_apply(slab[a:a + W * D + T], w * S * D, ratio)
+        k, dec = O.lowpass_block(taps, D, raw)
+        assert k == W
+        rows.append(O.norm(O.fft(dec))[np.r_[W // 2:W, 0:W // 2]])
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array(rows, dtype=np.float32).reshape(-1, W))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cfg", [
+    (2, (280000, (200_000, 32, 400), 64, 16)),     # cfg 5's chain: halo (W-S)*D + T = 1936 samples
+    (3, (280000, (2_000_000, 16, 40), 128, 128)),  # cfg 2's chain: halo T = 40
+])
+def test_sharded_equals_whole(tmp_path, oracle, world, cfg):
+    import torch.multiprocessing as mp
+    n = 120_000
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, cfg, str(tmp_path)), nprocs=world, join=True)
+    shift, (fc, D, T), W, S = cfg
+    rng = np.random.default_rng(1234)
+    x = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)
+    whole, _ = oracle.Chain.from_bytes(x.tobytes(), 0, 21_000_000).shift(shift).lowpass(fc, D, T).spark_fft(W, S)
+    parts = np.concatenate([np.load(os.path.join(str(tmp_path), f"rank{r}.npy")) for r in range(world)])
+    assert parts.shape == whole.shape
+    assert np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
+
+
+def test_partition_properties():
+    from quadrs_amd import shard as SH
+    for n_windows, world, step, rpw, tile in ((65535, 8, 2048, 2088, 2), (16777212, 8, 512, 2448, 4), (10, 4, 8, 40, 1),
+                                              (3, 8, 512, 2448, 4), (995, 2, 2, 4, 64)):
+        sh = SH.partition(n_windows, world, step, rpw, tile)
+        assert sh[0].w0 == 0 and sh[-1].w1 == n_windows
+        assert all(a.w1 == b.w0 for a, b in zip(sh, sh[1:]))
+        total_end = (n_windows - 1) * step + rpw
+        live = [s for s in sh if s.w1 > s.w0]
+        assert sum(s.own_count for s in live) == total_end                  # disjoint cover
+        for s in live:
+            assert s.need_first == s.w0 * step
+            assert s.need_first + s.need_count == (s.w1 - 1) * step + rpw
+        assert live[-1].halo == 0
+    sh = SH.partition(16777212 * 2 + 4, 8, 512, 2448, 4)                     # cfg 5: 1936-sample halo
+    assert {s.halo for s in sh[:-1]} == {1936}
