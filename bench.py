@@ -206,7 +206,7 @@ def main():
                          "kernel": "qd::k_chain", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
-            nwin_cpu = min(nw, 1 << 15)
+            nwin_cpu = min(nw, 1 << 18)
             first, count = plan.src_range(me.w0 + (nw - nwin_cpu) // 2, nwin_cpu)
             host = slab[(first - me.need_first) * bps:(first - me.need_first + count) * bps].cpu().numpy().tobytes()
             line["cpu_baseline"] = cpu_baseline(cfg, host, args.cpu_seconds)

@@ -57,6 +57,14 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python quadrs_amd/build.py` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64 (SONAME libamdhip64.so.7,
+        # but its dependants ask for "libamdhip64.so"), so if this library were loaded first the
+        # process would end up with two runtimes and torch tensors / streams could not be shared.
+        # Importing torch first makes our DT_NEEDED libamdhip64.so.7 resolve to torch's copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:      # a torch-less host (e.g. the C++ CLI) simply uses /opt/rocm's runtime
+            pass
         L = C.CDLL(LIB_PATH)
         vp, u64, i64, sz, f32, f64, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_size_t, C.c_float, C.c_double, C.c_int
         sig = {

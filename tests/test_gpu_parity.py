@@ -257,7 +257,20 @@ def test_glyph_and_bucket_epilogues(engine, oracle, fsk):
     vals = pb.run_host(data)
     ref_vals = ch.freq_levels(32, 8)
     assert pb.n_windows == ref_vals.size == (ch.len() - 32) // 8   # floor count, not the strict-< loop
-    assert (vals == ref_vals).mean() >= 0.9995 and 0 < ref_vals.mean() < 1
+    assert (vals == ref_vals).mean() >= 0.9995
+    # a stream whose tone hops between +f and -f exercises both digits (README's OOK/FSK use of `bucket`)
+    t = np.arange(60_000)
+    f = np.where((t // 5000) % 2 == 0, 0.11, -0.17)
+    z = 0.3 * np.exp(2j * np.pi * np.cumsum(f))
+    x = np.stack([z.real, z.imag], axis=1).astype(np.float32)
+    for lp in (None, (2_000_000, 4, 40)):
+        ch2 = oracle.Chain.from_bytes(x.tobytes(), 0, 21_000_000)
+        if lp:
+            ch2 = ch2.lowpass(*lp)
+        ref2 = ch2.freq_levels(64, 16)
+        got2 = engine.Plan(0, 21_000_000, x.shape[0], lowpass=lp, width=64, stride=16,
+                           epilogue=engine.EPI_BUCKET2_U8).run_host(x.tobytes())
+        assert np.array_equal(got2, ref2) and 0.2 < ref2.mean() < 0.8
 
 
 def test_window_subranges_and_slabs_concatenate(engine, oracle):
