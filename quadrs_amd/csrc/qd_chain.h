@@ -2,9 +2,10 @@
 //
 // One workgroup (256 threads) owns a *tile* of G consecutive FFT windows of the sink's loop
 // (spark_fft, src/fft.rs:28-65).  Per tile:
-//   phase 1  stream the tile's contiguous raw range from HBM (16-byte coalesced loads), unpack,
-//            multiply by the NCO, park the shifted cf32 samples in LDS (row-padded so that the
-//            FIR's stride-D lane pattern is bank-conflict free);
+//   phase 1  stream the tile's contiguous raw range from HBM (16-byte coalesced loads, prefetched
+//            into registers one tile / several rows ahead), unpack, multiply by the NCO, park the
+//            shifted cf32 samples in LDS (row-padded so that the FIR's stride-D lane pattern is
+//            bank-conflict free);
 //   phase 2  FIR+decimate, one lane per decimated output, taps ascending, separately rounded
 //            mul/add — the reference's summation order (src/filter.rs:111-121), including its
 //            per-read_at tail truncation (jmax), results scattered into the FFT buffer in
@@ -14,6 +15,11 @@
 //   phase 4  fftshift + hypot (+ glyph / bucket) and a coalesced store.
 // Decimated samples never leave the CU.  Windows are independent units, so tiles need no
 // inter-workgroup communication; the grid is sized to the chip and strides over tiles.
+//
+// The kernel is written once against a geometry policy: FixedGeo<W,S,D,T,G> turns every shape
+// parameter into a compile-time constant (LDS offsets become immediates, the FIR unrolls, index
+// math folds away) and is instantiated for common chain shapes; DynGeo reads the same quantities
+// from the launch parameters and serves every other shape.
 #pragma once
 
 #include "qd_device.h"
@@ -29,95 +35,317 @@ typedef const double __attribute__((address_space(4))) *const_f64_p;
 
 // samples per lane per row-load, by format
 template <int FMT> struct FmtTraits;
-template <> struct FmtTraits<0> { static constexpr int BPS = 8; static constexpr int SPL = 2; };  // cf32: 16 B / lane
-template <> struct FmtTraits<1> { static constexpr int BPS = 2; static constexpr int SPL = 4; };  // cs8 :  8 B / lane
-template <> struct FmtTraits<2> { static constexpr int BPS = 2; static constexpr int SPL = 4; };  // cu8 :  8 B / lane
-template <> struct FmtTraits<3> { static constexpr int BPS = 4; static constexpr int SPL = 4; };  // cs16: 16 B / lane
+template <> struct FmtTraits<0> { static constexpr int BPS = 8; static constexpr int SPL = 2; using Vec = uint4; };  // cf32: 16 B / lane
+template <> struct FmtTraits<1> { static constexpr int BPS = 2; static constexpr int SPL = 4; using Vec = uint2; };  // cs8 :  8 B / lane
+template <> struct FmtTraits<2> { static constexpr int BPS = 2; static constexpr int SPL = 4; using Vec = uint2; };  // cu8 :  8 B / lane
+template <> struct FmtTraits<3> { static constexpr int BPS = 4; static constexpr int SPL = 4; using Vec = uint4; };  // cs16: 16 B / lane
 
 struct ChainParams {
+    // ---- per launch
     const uint8_t *src;        // raw bytes of sample src_first
     uint64_t src_first;
     uint64_t src_count;
     uint64_t first_window;     // of this launch
     uint64_t n_windows;
     uint64_t out_window0;      // window index that maps to out[0]
-    uint32_t W, logW, S, D, T, c, G;
-    uint32_t Dp;               // LDS row pitch: D + 1 if D even else D
-    uint32_t dmagic;           // floor(2^32 / D) + 1  (exact m / D for m*D < 2^32)
-    uint32_t a0, b0;           // c = a0*D + b0
-    uint32_t T_fast;           // min(T, D + T/2): every output's jmax is >= this
-    uint32_t a1, b1;           // c + T_fast = a1*D + b1
-    uint32_t base_len, log_base, layers; // rustfft Radix4 plan: W = base_len * 4^layers
-    uint32_t vec_ok;           // vector loads are aligned
-    uint32_t second_order;     // NCO second-order correction
-    uint32_t epi;              // qd_epilogue
-    uint32_t lds_raw_elems;    // float2 capacity of the raw tile
-    float rmin, rmax;
-    float root2;
-    float2 tw16_1, tw16_2, tw16_3;
-    double ratio;
+    void *out;
     const RowBase *rowtab;     // indexed by absolute row - rowtab_row0
     uint64_t rowtab_row0;
     const double2 *jtab;       // ROW entries (cos, sin)(fl(j*ratio))
     const float *taps;
     const float2 *tw;          // radix-4 layer twiddles, bottom layer first
-    void *out;
+    double ratio;
+    float rmin, rmax;
+    float root2;
+    float2 tw16_1, tw16_2, tw16_3;
+    uint32_t epi;              // qd_epilogue
+    uint32_t dbg;              // timing-only ablation bits (QD_DEBUG_SKIP); 0 in every real run
+    // ---- geometry (only DynGeo reads these; FixedGeo has them as constants)
+    uint32_t W, logW, S, D, T, G;
+    uint32_t Dp;               // LDS row pitch: D + 1 if D even else D
+    uint32_t dmagic;           // floor(2^32 / D) + 1  (exact m / D for m*D < 2^32)
+    uint32_t dshift;           // log2(D) if D is a power of two, else 0xffffffff
+    uint32_t a0, b0;           // c = T - T/2 = a0*D + b0
+    uint32_t T_fast;           // min(T, D + T/2): every output's jmax is >= this
+    uint32_t a1, b1;           // c + T_fast = a1*D + b1
+    uint32_t base_len, log_base, layers;   // rustfft Radix4 plan: W = base_len * 4^layers
+    uint32_t lds_raw_elems;    // float2 capacity of the raw tile
 };
 
-template <int FMT>
-__device__ __forceinline__ float2 load_sample_scalar(const uint8_t *src, uint64_t idx, const float *lut) {
-    if constexpr (FMT == 0) {
-        return *reinterpret_cast<const float2 *>(src + idx * 8);
-    } else if constexpr (FMT == 1 || FMT == 2) {
-        uint16_t v = *reinterpret_cast<const uint16_t *>(src + idx * 2);
-        return make_float2(lut[v & 0xff], lut[v >> 8]);
-    } else {
-        uint32_t v = *reinterpret_cast<const uint32_t *>(src + idx * 4);
-        return make_float2(unpack_cs16(v & 0xffffu), unpack_cs16(v >> 16));
-    }
+// ---------------------------------------------------------------- geometry policies
+
+constexpr uint32_t ct_log2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) ++l; return l; }
+constexpr bool ct_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+constexpr uint32_t ct_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// LDS float2 elements the raw tile needs (same formula as the host's lds_for())
+constexpr uint32_t ct_raw_elems(uint32_t W, uint32_t S, uint32_t D, uint32_t T, uint32_t G) {
+    uint32_t tile_raw = (G - 1) * S * D + W * D + T;
+    uint32_t pad = (D % 2 == 0) ? tile_raw / D + 1 : 0;
+    uint32_t elems = tile_raw + pad + 1;
+    uint32_t min_elems = G * W / 2 + 1;
+    if (elems < min_elems) elems = min_elems;
+    return (elems + 1) & ~1u;
 }
 
-// FIR over taps [j0, j1) for one output; (rowp, b) is the LDS position of tap j0.
-// Control flow is wave-uniform; only rowp and jmax differ per lane.
-template <bool PRED>
-__device__ __forceinline__ void fir_span(const float2 *rowp, uint32_t b, uint32_t j0, uint32_t j1, uint32_t jmax,
-                                         uint32_t D, uint32_t Dp, const float *__restrict__ taps,
-                                         float &accr, float &acci) {
-    uint32_t j = j0;
-    while (j < j1) {
-        uint32_t run = D - b;
-        if (run > j1 - j) run = j1 - j;
-        const float2 *p = rowp + b;
-        const_f32_p h = (const_f32_p)(uintptr_t)(taps + j);
-#pragma unroll 8
-        for (uint32_t i = 0; i < run; ++i) {
-            float2 x = p[i];
-            float hh = h[i];
-            if (!PRED || (j + i) < jmax) {
-                accr = accr + x.x * hh;   // Complex<f32> * f32, then +=  (src/filter.rs:119)
-                acci = acci + x.y * hh;
+template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_>
+struct FixedGeo {
+    static constexpr bool kFixed = true;
+    __device__ __forceinline__ explicit FixedGeo(const ChainParams &) {}
+    static constexpr uint32_t W = W_, S = S_, D = D_, T = T_, G = G_;
+    static constexpr uint32_t logW = ct_log2(W_);
+    static constexpr uint32_t Dp = D_ + ((D_ % 2 == 0) ? 1u : 0u);
+    static constexpr uint32_t dshift = ct_pow2(D_) ? ct_log2(D_) : 0xffffffffu;
+    static constexpr uint32_t dmagic = D_ > 1 ? (uint32_t)((1ull << 32) / D_ + 1) : 0u;
+    static constexpr uint32_t c = T_ - T_ / 2;
+    static constexpr uint32_t a0 = c / D_, b0 = c % D_;
+    static constexpr uint32_t T_fast = ct_min(T_, D_ + T_ / 2);
+    static constexpr uint32_t a1 = (c + T_fast) / D_, b1 = (c + T_fast) % D_;
+    static constexpr uint32_t log_base = logW <= 3 ? logW : ((logW & 1) ? 3u : 4u);
+    static constexpr uint32_t base_len = 1u << log_base;
+    static constexpr uint32_t layers = (logW - log_base) / 2;
+    static constexpr uint32_t lds_raw_elems = ct_raw_elems(W_, S_, D_, T_, G_);
+};
+
+struct DynGeo {
+    static constexpr bool kFixed = false;
+    uint32_t W, S, D, T, G, logW, Dp, dshift, dmagic, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
+    __device__ __forceinline__ explicit DynGeo(const ChainParams &P)
+        : W(P.W), S(P.S), D(P.D), T(P.T), G(P.G), logW(P.logW), Dp(P.Dp), dshift(P.dshift), dmagic(P.dmagic),
+          a0(P.a0), b0(P.b0), T_fast(P.T_fast), a1(P.a1), b1(P.b1), log_base(P.log_base), base_len(P.base_len),
+          layers(P.layers), lds_raw_elems(P.lds_raw_elems) {}
+};
+
+// ---------------------------------------------------------------- phase-1 helpers
+// A "row" is kThreads*SPL consecutive samples starting at an absolute multiple of ROW.
+
+struct TileGeo {            // everything wave-uniform
+    uint64_t w0, n_start;
+    uint64_t r0;            // first absolute row touching the tile
+    int64_t row0_off;       // byte offset of row r0 inside the slab (may be negative)
+    uint32_t n_rows;        // rows touching the tile
+    uint32_t g_cnt, tile_raw;
+    int32_t rel0;           // r0*ROW - n_start  (in (-ROW, 0])
+    bool valid;
+};
+
+template <int FMT, class GeoT>
+__device__ __forceinline__ TileGeo tile_geo(const ChainParams &P, const GeoT &geo, uint64_t tile, uint64_t n_tiles) {
+    constexpr uint32_t ROW = kThreads * FmtTraits<FMT>::SPL;
+    constexpr int BPS = FmtTraits<FMT>::BPS;
+    TileGeo g;
+    g.valid = tile < n_tiles;
+    g.w0 = P.first_window + tile * geo.G;
+    const uint64_t left = P.first_window + P.n_windows - g.w0;
+    g.g_cnt = (!g.valid) ? 0u : (left < geo.G ? (uint32_t)left : geo.G);
+    g.n_start = g.w0 * ((uint64_t)geo.S * geo.D);                    // LowPass reads inner at off*D (src/filter.rs:71)
+    g.tile_raw = g.valid ? (g.g_cnt - 1) * geo.S * geo.D + geo.W * geo.D + geo.T : 0u;   // B*D + T (src/filter.rs:68)
+    g.r0 = g.n_start / ROW;
+    g.rel0 = (int32_t)(int64_t)(g.r0 * ROW - g.n_start);
+    g.n_rows = (uint32_t)((g.tile_raw - g.rel0 + ROW - 1) / ROW);
+    g.row0_off = ((int64_t)(g.r0 * ROW) - (int64_t)P.src_first) * BPS;
+    return g;
+}
+
+// Issue this lane's load for row i of the tile (the result stays in flight until first use).
+// ALIGNED: ONE unconditional vector load per lane.  The lane offset is clamped into the slab with two
+// 32-bit min/max against wave-uniform bounds, so lanes outside the slab (their data is never used)
+// stay in bounds, there is no branch, and the load writes its destination register directly —
+// nothing forces an early s_waitcnt.  The host never hands this path a vector that straddles the
+// slab end.  !ALIGNED (slab start not vector aligned): per-sample loads, correctness path.
+template <int FMT, bool ALIGNED>
+__device__ __forceinline__ typename FmtTraits<FMT>::Vec fetch_row(const ChainParams &P, const TileGeo &g, uint32_t i,
+                                                                    uint32_t tid) {
+    using FT = FmtTraits<FMT>;
+    using Vec = typename FT::Vec;
+    constexpr int SPL = FT::SPL, BPS = FT::BPS;
+    constexpr int32_t ROWB = kThreads * SPL * BPS, VECB = SPL * BPS;
+    if constexpr (ALIGNED) {
+        const int64_t row_off = g.row0_off + (int64_t)i * ROWB;                                    // uniform
+        const int64_t hi = (int64_t)P.src_count * BPS - VECB;                                      // last legal offset
+        int64_t lo_rel = -row_off, hi_rel = hi - row_off;                                          // uniform, clamp to i32
+        lo_rel = lo_rel < 0 ? 0 : (lo_rel > ROWB ? ROWB : lo_rel);
+        hi_rel = hi_rel > ROWB ? ROWB : (hi_rel < -ROWB ? -ROWB : hi_rel);
+        int32_t t = (int32_t)(tid * VECB);
+        t = t < (int32_t)lo_rel ? (int32_t)lo_rel : t;
+        t = t > (int32_t)hi_rel ? (int32_t)hi_rel : t;
+        const uint8_t *rowp = P.src + row_off;                                                     // uniform base
+        return *reinterpret_cast<const Vec *>(rowp + t);
+    } else {
+        const int32_t m0 = g.rel0 + (int32_t)(i * (kThreads * SPL)) + (int32_t)(tid * SPL);
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            const int32_t m = m0 + u;
+            if (m >= 0 && m < (int32_t)g.tile_raw) {        // samples inside the tile are inside the slab
+                const uint8_t *sp = P.src + (g.n_start + (uint32_t)m - P.src_first) * BPS;
+                if constexpr (FMT == 0) { uint2 t = *reinterpret_cast<const uint2 *>(sp); w[2 * u] = t.x; w[2 * u + 1] = t.y; }
+                else if constexpr (FMT == 3) { w[u] = *reinterpret_cast<const uint32_t *>(sp); }
+                else { uint32_t t = *reinterpret_cast<const uint16_t *>(sp); w[u >> 1] |= t << (16 * (u & 1)); }
             }
         }
-        j += run;
-        b = 0;
-        rowp += Dp;
+        Vec v{};
+        if constexpr (sizeof(Vec) == 16) { v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3]; }
+        else { v.x = w[0]; v.y = w[1]; }
+        return v;
     }
 }
 
-template <int FMT, bool HAS_SHIFT, bool HAS_FIR>
-__global__ __launch_bounds__(kThreads) void k_chain(const ChainParams P) {
+// scalar (wave-uniform) load of one row base
+__device__ __forceinline__ RowBase load_rowbase(const ChainParams &P, uint64_t r) {
+    const_f64_p rp = (const_f64_p)(uintptr_t)(P.rowtab + (r - P.rowtab_row0));
+    RowBase rb;
+    rb.c = rp[0]; rb.s = rp[1]; rb.theta = rp[2]; rb.nf = rp[3];
+    return rb;
+}
+
+// tile-relative sample index m -> row-padded LDS element  m + (m / D) * (Dp - D)   (Dp - D is 0 or 1)
+template <class GeoT>
+__device__ __forceinline__ uint32_t pad_index(const GeoT &geo, uint32_t m) {
+    if (geo.Dp == geo.D) return m;
+    if (geo.dshift != 0xffffffffu) return m + (m >> geo.dshift);
+    return m + __umulhi(m, geo.dmagic);
+}
+
+// unpack -> NCO -> park in LDS for one fetched row.
+// NCO: 0 = no shift, 1 = first-order, 2 = second-order correction.  INTERIOR rows lie wholly
+// inside the tile, so no per-sample bounds checks are needed (a wave-uniform property).
+template <int FMT, int NCO, bool INTERIOR, class GeoT>
+__device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &geo, const TileGeo &g, int32_t rel,
+                                            uint32_t tid, const typename FmtTraits<FMT>::Vec &v, const RowBase &rb,
+                                            const LaneRot *lr, uint32_t lane_pad, const float *lut, float2 *raw) {
     using FT = FmtTraits<FMT>;
     constexpr int SPL = FT::SPL;
-    constexpr int BPS = FT::BPS;
     constexpr uint32_t ROW = kThreads * SPL;
+    const int32_t m0 = rel + (int32_t)(tid * SPL);
+    if constexpr (!INTERIOR) {
+        if (!(m0 + SPL > 0 && m0 < (int32_t)g.tile_raw)) return;
+    }
+    float2 x[SPL];
+    if constexpr (FMT == 0) {
+        x[0] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+        x[1] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
+    } else if constexpr (FMT == 1 || FMT == 2) {
+        x[0] = make_float2(lut[v.x & 0xff], lut[(v.x >> 8) & 0xff]);
+        x[1] = make_float2(lut[(v.x >> 16) & 0xff], lut[v.x >> 24]);
+        x[2] = make_float2(lut[v.y & 0xff], lut[(v.y >> 8) & 0xff]);
+        x[3] = make_float2(lut[(v.y >> 16) & 0xff], lut[v.y >> 24]);
+    } else {
+        x[0] = make_float2(unpack_cs16(v.x & 0xffffu), unpack_cs16(v.x >> 16));
+        x[1] = make_float2(unpack_cs16(v.y & 0xffffu), unpack_cs16(v.y >> 16));
+        x[2] = make_float2(unpack_cs16(v.z & 0xffffu), unpack_cs16(v.z >> 16));
+        x[3] = make_float2(unpack_cs16(v.w & 0xffffu), unpack_cs16(v.w >> 16));
+    }
+    if constexpr (NCO != 0) {
+        if (!(P.dbg & 1)) {
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                float2 m = nco_mul<NCO == 2>(rb, lr[u], P.ratio);
+                x[u] = cmul(x[u], m);                              // buf[i] *= mul (src/shift.rs:51)
+            }
+        }
+    }
+    // Additive addressing: rel is a multiple of D (n_start and ROW both are) and SPL divides D, so
+    // pad(rel + t) = pad_s(rel) + pad(t) and a lane's SPL samples are contiguous in LDS.
+    const bool additive = geo.dshift != 0xffffffffu && geo.D >= (uint32_t)SPL && geo.D <= ROW;
+    if (additive) {
+        const int32_t row_pad = rel + ((geo.Dp != geo.D) ? (rel >> geo.dshift) : 0);      // uniform, signed
+        float2 *dst = raw + (row_pad + (int32_t)lane_pad);
+#pragma unroll
+        for (int u = 0; u < SPL; ++u)
+            if (INTERIOR || (m0 + u >= 0 && m0 + u < (int32_t)g.tile_raw)) dst[u] = x[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            const int32_t m = m0 + u;
+            if (INTERIOR || (m >= 0 && m < (int32_t)g.tile_raw)) raw[pad_index(geo, (uint32_t)m)] = x[u];
+        }
+    }
+}
+
+template <int FMT, int NCO, class GeoT>
+__device__ __forceinline__ void process_row_any(const ChainParams &P, const GeoT &geo, const TileGeo &g, uint32_t i,
+                                                uint32_t tid, const typename FmtTraits<FMT>::Vec &v, const RowBase &rb,
+                                                const LaneRot *lr, uint32_t lane_pad, const float *lut, float2 *raw) {
+    constexpr uint32_t ROW = kThreads * FmtTraits<FMT>::SPL;
+    const int32_t rel = g.rel0 + (int32_t)(i * ROW);                                              // wave-uniform
+    if (rel >= 0 && rel + (int32_t)ROW <= (int32_t)g.tile_raw)
+        process_row<FMT, NCO, true>(P, geo, g, rel, tid, v, rb, lr, lane_pad, lut, raw);
+    else
+        process_row<FMT, NCO, false>(P, geo, g, rel, tid, v, rb, lr, lane_pad, lut, raw);
+}
+
+// ---------------------------------------------------------------- FIR
+// Taps [j0, j1) for one output; rowp points at the LDS row (of D samples, pitch Dp) holding tap j0
+// at column b.  Control flow is wave-uniform; only rowp and jmax differ per lane.  With FixedGeo
+// all bounds are constants and both loops unroll completely (LDS offsets become immediates).
+template <bool PRED, class GeoT>
+__device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, uint32_t b, uint32_t j0, uint32_t j1,
+                                         uint32_t jmax, const float *__restrict__ taps, float &accr, float &acci) {
+    const uint32_t D = geo.D, Dp = geo.Dp;
+    const uint32_t n = j1 - j0;                       // taps to do
+    const uint32_t n_rows = (b + n + D - 1) / D;      // LDS rows touched
+    const_f32_p h = (const_f32_p)(uintptr_t)(taps + j0);
+    if constexpr (GeoT::kFixed) {
+#pragma unroll
+        for (uint32_t a = 0; a < n_rows; ++a) {
+            const uint32_t bs = a == 0 ? b : 0;
+            const uint32_t be = (b + n - a * D) < D ? (b + n - a * D) : D;
+#pragma unroll
+            for (uint32_t bb = bs; bb < be; ++bb) {
+                const uint32_t jj = a * D + bb - b;   // tap index relative to j0
+                float2 x = rowp[a * Dp + bb];
+                float hh = h[jj];
+                if (!PRED || (j0 + jj) < jmax) {
+                    accr = accr + x.x * hh;           // Complex<f32> * f32, then +=  (src/filter.rs:119)
+                    acci = acci + x.y * hh;
+                }
+            }
+        }
+    } else {
+        uint32_t j = 0;
+        while (j < n) {
+            uint32_t run = D - b;
+            if (run > n - j) run = n - j;
+            const float2 *p = rowp + b;
+#pragma unroll 8
+            for (uint32_t i = 0; i < run; ++i) {
+                float2 x = p[i];
+                float hh = h[j + i];
+                if (!PRED || (j0 + j + i) < jmax) {
+                    accr = accr + x.x * hh;
+                    acci = acci + x.y * hh;
+                }
+            }
+            j += run;
+            b = 0;
+            rowp += Dp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- the kernel
+// RCH / WHOLE: prefetch geometry.
+//   WHOLE (rows per tile <= RCH): slot i holds row i of the workgroup's *next* tile; it is refilled
+//   right after row i of the current tile has been consumed, so a full tile of loads is in flight
+//   during the FIR/FFT phases (prefetch distance = one tile).
+//   Chunked (bigger tiles): RCH rows ahead within the tile, the next tile's first chunk at its end.
+// LB: waves per SIMD the build is register-budgeted for (__launch_bounds__ 2nd argument).
+template <int FMT, int NCO, class GeoT, bool HAS_FIR, int RCH, bool WHOLE, bool ALIGNED, int LB>
+__global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
+    using FT = FmtTraits<FMT>;
+    using Vec = typename FT::Vec;
+    constexpr int SPL = FT::SPL;
+    constexpr bool HAS_SHIFT = NCO != 0;
+    const GeoT geo(P);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
-    float2 *fb = raw + P.lds_raw_elems;
-    float *lut = reinterpret_cast<float *>(fb + (size_t)P.G * P.W);
+    float2 *fb = raw + geo.lds_raw_elems;
+    float *lut = reinterpret_cast<float *>(fb + (size_t)geo.G * geo.W);
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t W = P.W, logW = P.logW, S = P.S, D = P.D, T = P.T, Dp = P.Dp;
+    const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
 
     if constexpr (FMT == 1) lut[tid] = unpack_cs8(tid);
     if constexpr (FMT == 2) lut[tid] = unpack_cu8(tid);
@@ -134,123 +362,103 @@ __global__ __launch_bounds__(kThreads) void k_chain(const ChainParams P) {
             lr[u].s = cs.y;
         }
     }
+    const uint32_t lane_pad = pad_index(geo, tid * SPL);      // LDS element of this lane's first sample in a row
     if constexpr (FMT == 1 || FMT == 2) __syncthreads();
 
-    const uint64_t n_tiles = (P.n_windows + P.G - 1) / P.G;
-    const uint64_t src_end = P.src_first + P.src_count;
+    const uint64_t n_tiles = (P.n_windows + geo.G - 1) / geo.G;
 
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t w0 = P.first_window + tile * P.G;
-        uint64_t left = P.first_window + P.n_windows - w0;
-        const uint32_t g_cnt = left < P.G ? (uint32_t)left : P.G;
-        const uint64_t n_start = w0 * S * D;                       // LowPass reads inner at off*D (src/filter.rs:71)
-        const uint32_t tile_raw = (g_cnt - 1) * S * D + W * D + T; // B*D + T per window (src/filter.rs:68)
-        const uint64_t n_end = n_start + tile_raw;
+    // Register prefetch pipeline.  Slots whose row does not exist in the tile re-load its last
+    // row (an L2 hit) so that every load stays unconditional.
+    uint64_t tile = blockIdx.x;
+    TileGeo tg = tile_geo<FMT>(P, geo, tile, n_tiles);
+    Vec pf[RCH];
+    if (tg.valid) {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, ALIGNED>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
+    }
+
+    while (tg.valid) {
+        const uint64_t w0 = tg.w0;
+        const uint32_t g_cnt = tg.g_cnt;
 
         // ---------------- phase 1: HBM -> unpack -> NCO -> LDS
-        const uint64_t r0 = n_start / ROW, r1 = (n_end + ROW - 1) / ROW;
-        for (uint64_t r = r0; r < r1; ++r) {
-            const uint64_t nrow = r * ROW;
-            const uint64_t n0 = nrow + (uint64_t)tid * SPL;
-            // wave-uniform skip of waves entirely outside the tile
-            const uint64_t wv0 = nrow + (uint64_t)(tid & ~63u) * SPL;
-            if (wv0 >= n_end || wv0 + 64 * SPL <= n_start) continue;
-            const bool any = (n0 + SPL > n_start) && (n0 < n_end);
-            if (!any) continue;
-
-            float2 x[SPL];
-            const bool whole = P.vec_ok && n0 >= P.src_first && n0 + SPL <= src_end;
-            if (whole) {
-                const uint8_t *p = P.src + (n0 - P.src_first) * BPS;
-                if constexpr (FMT == 0) {
-                    float4 v = *reinterpret_cast<const float4 *>(p);
-                    x[0] = make_float2(v.x, v.y);
-                    x[1] = make_float2(v.z, v.w);
-                } else if constexpr (FMT == 1 || FMT == 2) {
-                    uint2 v = *reinterpret_cast<const uint2 *>(p);
-                    x[0] = make_float2(lut[v.x & 0xff], lut[(v.x >> 8) & 0xff]);
-                    x[1] = make_float2(lut[(v.x >> 16) & 0xff], lut[v.x >> 24]);
-                    x[2] = make_float2(lut[v.y & 0xff], lut[(v.y >> 8) & 0xff]);
-                    x[3] = make_float2(lut[(v.y >> 16) & 0xff], lut[v.y >> 24]);
-                } else {
-                    uint4 v = *reinterpret_cast<const uint4 *>(p);
-                    x[0] = make_float2(unpack_cs16(v.x & 0xffffu), unpack_cs16(v.x >> 16));
-                    x[1] = make_float2(unpack_cs16(v.y & 0xffffu), unpack_cs16(v.y >> 16));
-                    x[2] = make_float2(unpack_cs16(v.z & 0xffffu), unpack_cs16(v.z >> 16));
-                    x[3] = make_float2(unpack_cs16(v.w & 0xffffu), unpack_cs16(v.w >> 16));
-                }
-            } else {
+        if constexpr (WHOLE) {
+            TileGeo ng = tile_geo<FMT>(P, geo, tile + gridDim.x, n_tiles);
+            if (!ng.valid) ng = tg;                  // last tile of this workgroup: harmless re-loads
 #pragma unroll
-                for (int u = 0; u < SPL; ++u) {
-                    uint64_t n = n0 + u;
-                    x[u] = (n >= n_start && n < n_end) ? load_sample_scalar<FMT>(P.src, n - P.src_first, lut)
-                                                        : make_float2(0.f, 0.f);
+            for (int i = 0; i < RCH; ++i) {
+                const Vec v = pf[i];
+                pf[i] = fetch_row<FMT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
+                if ((uint32_t)i < tg.n_rows) {
+                    RowBase rb{};
+                    if constexpr (HAS_SHIFT) rb = load_rowbase(P, tg.r0 + i);
+                    process_row_any<FMT, NCO>(P, geo, tg, i, tid, v, rb, lr, lane_pad, lut, raw);
                 }
             }
-
-            if constexpr (HAS_SHIFT) {
-                const_f64_p rp = (const_f64_p)(uintptr_t)(P.rowtab + (r - P.rowtab_row0));   // uniform: scalar loads
-                RowBase rb;
-                rb.c = rp[0]; rb.s = rp[1]; rb.theta = rp[2]; rb.nf = rp[3];
+        } else {
+            for (uint32_t r = 0; r < tg.n_rows; r += RCH) {
+                Vec cur[RCH];
 #pragma unroll
-                for (int u = 0; u < SPL; ++u) {
-                    float2 m = nco_mul(rb, lr[u], P.ratio, P.second_order != 0);
-                    x[u] = cmul(x[u], m);                          // buf[i] *= mul (src/shift.rs:51)
+                for (int i = 0; i < RCH; ++i) cur[i] = pf[i];
+                TileGeo ng = tg;
+                uint32_t rbase = r + RCH;
+                if (rbase >= tg.n_rows) {
+                    const TileGeo t2 = tile_geo<FMT>(P, geo, tile + gridDim.x, n_tiles);
+                    if (t2.valid) { ng = t2; rbase = 0; } else { rbase = tg.n_rows - 1; }
                 }
-            }
-
-            // tile-relative index -> padded LDS position  m + (m / D) * (Dp - D)
-            int64_t mrel = (int64_t)(n0 - n_start);
 #pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                int64_t m = mrel + u;
-                if (m >= 0 && m < (int64_t)tile_raw) {
-                    uint32_t mu = (uint32_t)m;
-                    uint32_t q = __umulhi(mu, P.dmagic);
-                    raw[mu + q * (Dp - D)] = x[u];
+                for (int i = 0; i < RCH; ++i)
+                    pf[i] = fetch_row<FMT, ALIGNED>(P, ng, rbase + i < ng.n_rows ? rbase + i : ng.n_rows - 1, tid);
+                RowBase rb[RCH];
+#pragma unroll
+                for (int i = 0; i < RCH; ++i) {
+                    rb[i] = RowBase{};
+                    if constexpr (HAS_SHIFT) { if (r + i < tg.n_rows) rb[i] = load_rowbase(P, tg.r0 + r + i); }
                 }
+#pragma unroll
+                for (int i = 0; i < RCH; ++i)
+                    if (r + i < tg.n_rows) process_row_any<FMT, NCO>(P, geo, tg, r + i, tid, cur[i], rb[i], lr, lane_pad, lut, raw);
             }
         }
         __syncthreads();
 
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
         const uint32_t n_out = g_cnt << logW;
-        const uint32_t log_width = 2 * P.layers;  // width = W / base_len = 4^layers
+        const uint32_t log_width = 2 * geo.layers;   // width = W / base_len = 4^layers
         for (uint32_t o = tid; o < n_out; o += kThreads) {
             const uint32_t g = o >> logW, k = o & (W - 1);
             const uint32_t q = g * S + k;
             float accr = 0.f, acci = 0.f;
-            if constexpr (HAS_FIR) {
+            if (HAS_FIR && !(P.dbg & 2)) {
                 // jmax(k) = min(T, valid - (k*D + c)) with valid = W*D + T (full read)
                 uint32_t jmax = (W - k) * D + T / 2;
                 if (jmax > T) jmax = T;
-                const float2 *rowp = raw + (size_t)(q + P.a0) * Dp;
-                const bool wave_full = __all(jmax == T);
-                if (wave_full) {
-                    fir_span<false>(rowp, P.b0, 0, T, T, D, Dp, P.taps, accr, acci);
+                const float2 *rowp = raw + (size_t)(q + geo.a0) * Dp;
+                if (geo.T_fast == T || __all(jmax == T)) {
+                    fir_span<false>(geo, rowp, geo.b0, 0, T, T, P.taps, accr, acci);
                 } else {
-                    fir_span<false>(rowp, P.b0, 0, P.T_fast, T, D, Dp, P.taps, accr, acci);
-                    const float2 *rowp1 = raw + (size_t)(q + P.a1) * Dp;
-                    fir_span<true>(rowp1, P.b1, P.T_fast, T, jmax, D, Dp, P.taps, accr, acci);
+                    fir_span<false>(geo, rowp, geo.b0, 0, geo.T_fast, T, P.taps, accr, acci);
+                    const float2 *rowp1 = raw + (size_t)(q + geo.a1) * Dp;
+                    fir_span<true>(geo, rowp1, geo.b1, geo.T_fast, T, jmax, P.taps, accr, acci);
                 }
             } else {
-                float2 v = raw[q];
+                float2 v = raw[HAS_FIR ? q * Dp : q];
                 accr = v.x; acci = v.y;
             }
             // bitreversed_transpose::<4>(base_len, ..): out[y + rev(x)*base] = in[x + y*width]
             const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
-            const uint32_t pos = yy + rev4(xx, P.layers) * P.base_len;
+            const uint32_t pos = yy + (rev4(xx, geo.layers) << geo.log_base);
             fb[(g << logW) + pos] = make_float2(accr, acci);
         }
         __syncthreads();
 
         // ---------------- phase 3: FFT (rustfft Radix4: base butterflies, then radix-4 layers)
-        {
-            const uint32_t base = P.base_len;
-            const uint32_t log_tpw = logW - P.log_base;   // base tasks per window = W / base
+        if (!(P.dbg & 4)) {
+            const uint32_t base = geo.base_len;
+            const uint32_t log_tpw = logW - geo.log_base;   // base tasks per window = W / base
             const uint32_t n_task = g_cnt << log_tpw;
             for (uint32_t t = tid; t < n_task; t += kThreads) {
-                // task t -> window t >> log_tpw, chunk t & (tpw-1): chunks are contiguous, so
+                // windows are contiguous in fb, so task t owns chunk t
                 float2 *d = fb + (size_t)t * base;
                 if (base == 16) {
                     float2 v[16];
@@ -276,13 +484,13 @@ __global__ __launch_bounds__(kThreads) void k_chain(const ChainParams P) {
                     d[0] = v0; d[1] = v1;
                 }
             }
-            uint32_t cols = base, log_cols = P.log_base;
+            uint32_t cols = base, log_cols = geo.log_base;
             const float2 *tw = P.tw;
-            for (uint32_t layer = 0; layer < P.layers; ++layer) {
+            for (uint32_t layer = 0; layer < geo.layers; ++layer) {
                 __syncthreads();
                 const uint32_t n_bf = (g_cnt << logW) >> 2;   // W/4 butterflies per window
                 for (uint32_t t = tid; t < n_bf; t += kThreads) {
-                    // butterfly t: chunk (of 4*cols, windows are contiguous) t >> log_cols, column t & (cols-1)
+                    // butterfly t: chunk (of 4*cols; windows are contiguous) t >> log_cols, column t & (cols-1)
                     const uint32_t chunk = t >> log_cols, i = t & (cols - 1);
                     float2 *d = fb + (size_t)chunk * 4 * cols + i;
                     float2 s0 = d[0];
@@ -299,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void k_chain(const ChainParams P) {
         }
         __syncthreads();
 
-        // ---------------- phase 4: fftshift + norm + epilogue
+        // ---------------- phase 4: fftshift + norm + epilogue (out index is tile base + o: coalesced)
         const uint64_t wrel = w0 - P.out_window0;
         if (P.epi == 2) {
             // freq_levels (src/fft.rs:95-97): sequential f32 sums of |X[k]| over each half
@@ -314,15 +522,18 @@ __global__ __launch_bounds__(kThreads) void k_chain(const ChainParams P) {
                 reinterpret_cast<uint8_t *>(P.out)[wrel + tid] = first < second ? 0 : 1;
             }
         } else {
+            float *outf = reinterpret_cast<float *>(P.out) + (wrel << logW);     // uniform base
+            uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << logW);
             for (uint32_t o = tid; o < n_out; o += kThreads) {
-                const uint32_t g = o >> logW, b = o & (W - 1);
-                const float nm = norm_ref(fb[(g << logW) + ((b + W / 2) & (W - 1))]);
-                const uint64_t oi = ((wrel + g) << logW) + b;
-                if (P.epi == 0) reinterpret_cast<float *>(P.out)[oi] = nm;
-                else reinterpret_cast<uint8_t *>(P.out)[oi] = glyph_code(nm, P.rmin, P.rmax);
+                const float2 xv = fb[o ^ (W >> 1)];           // fftshift: bin (b + W/2) mod W of the same window
+                const float nm = (P.dbg & 8) ? xv.x : norm_ref(xv);
+                if (P.epi == 0) outf[o] = nm;
+                else outb[o] = glyph_code(nm, P.rmin, P.rmax);
             }
         }
         __syncthreads();
+        tile += gridDim.x;
+        tg = tile_geo<FMT>(P, geo, tile, n_tiles);
     }
 }
 

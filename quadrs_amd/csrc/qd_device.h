@@ -143,13 +143,14 @@ struct LaneRot { double jf, tj, c, s; };
 // d = tj + e with |e| <= ~ulp(place): cos/sin(d) from the lane constants plus a first or
 // second order correction in e.  Total error ~4e-16, so the f32 rounding equals glibc's
 // except when the f64 value lies within ~1e-8 f32-ulp of a rounding boundary.
-__device__ __forceinline__ float2 nco_mul(const RowBase &rb, const LaneRot &lr, double ratio, bool second_order) {
+template <bool SECOND_ORDER>
+__device__ __forceinline__ float2 nco_mul(const RowBase &rb, const LaneRot &lr, double ratio) {
     double nf = rb.nf + lr.jf;          // exact (integers < 2^53)
     double place = nf * ratio;          // == reference `place`
     double d = place - rb.theta;        // exact (Sterbenz)
     double e = d - lr.tj;               // exact
     double cd, sd;
-    if (second_order) {
+    if constexpr (SECOND_ORDER) {
         double h = 0.5 * e;
         double u = __builtin_fma(h, lr.c, lr.s);
         double v = __builtin_fma(-h, lr.s, lr.c);

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_shift(float2 *buf, uint64_t abs_off, ui
         for (int u = 0; u < 2; ++u) {
             uint64_t idx = (row0 + r) * ROW + tid * 2 + u;
             if (idx >= abs_off && idx < abs_off + n) {
-                float2 m = nco_mul(rb, lr[u], ratio, second_order != 0);
+                float2 m = second_order ? nco_mul<true>(rb, lr[u], ratio) : nco_mul<false>(rb, lr[u], ratio);
                 buf[idx - abs_off] = cmul(buf[idx - abs_off], m);
             }
         }
@@ -196,15 +197,67 @@ FftLayout fft_layout(uint64_t W) {
 
 typedef void (*chain_fn)(const ChainParams);
 
-chain_fn pick_kernel(int fmt, bool shift, bool fir) {
-#define QD_PICK(F)                                                                \
-    case F:                                                                       \
-        return shift ? (fir ? k_chain<F, true, true> : k_chain<F, true, false>)   \
-                     : (fir ? k_chain<F, false, true> : k_chain<F, false, false>);
-    switch (fmt) {
-        QD_PICK(0) QD_PICK(1) QD_PICK(2) QD_PICK(3)
+#ifdef QD_DEV_FAST   // development builds: cf32 only, to keep hipcc turnaround short
+#define QD_FMT_CASES(X) case 0: return X(0);
+#else
+#define QD_FMT_CASES(X) case 0: return X(0); case 1: return X(1); case 2: return X(2); case 3: return X(3);
+#endif
+
+// ---- generic kernels (DynGeo): every shape; chunked prefetch of 4 rows; aligned / unaligned slab
+template <int F, int NCO, bool FI>
+chain_fn pick_dyn(bool aligned) {
+    return aligned ? k_chain<F, NCO, DynGeo, FI, 4, false, true, 4> : k_chain<F, NCO, DynGeo, FI, 4, false, false, 4>;
+}
+
+template <int F>
+chain_fn pick_fmt(int nco, bool fir, bool aligned) {
+    switch (nco) {
+    case 0: return fir ? pick_dyn<F, 0, true>(aligned) : pick_dyn<F, 0, false>(aligned);
+    case 1: return fir ? pick_dyn<F, 1, true>(aligned) : pick_dyn<F, 1, false>(aligned);
+    default: return fir ? pick_dyn<F, 2, true>(aligned) : pick_dyn<F, 2, false>(aligned);
     }
-#undef QD_PICK
+}
+
+chain_fn pick_generic(int fmt, int nco, bool fir, bool aligned) {
+#define QD_X(F) pick_fmt<F>(nco, fir, aligned)
+    switch (fmt) { QD_FMT_CASES(QD_X) }
+#undef QD_X
+    return nullptr;
+}
+
+// ---- shape-specialised kernels (FixedGeo): the chain shapes of BASELINE.json / the README.
+// Same source as the generic kernel with W,S,D,T,G as compile-time constants.
+struct FixedEntry {
+    int fmt, nco;
+    uint32_t W, S, D, T, G;
+    int wg_per_cu;       // register budget the build targets (waves per SIMD == 256-thread blocks per CU)
+    chain_fn fn;
+    const char *name;
+};
+#define QD_FIXED(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NAME) \
+    { F, NCO, W, S, D, T, G, LB, k_chain<F, NCO, FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
+const FixedEntry kFixed[] = {
+    // configs[1]  "shift 280000 | lowpass -power 20 -decimate 16 2000000 | sparkfft -width 128"   (README.md:57-63)
+    QD_FIXED(0, 1, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
+    QD_FIXED(0, 2, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
+    // north_star target sentence: 200-tap FIR decimate 32 -> 128-pt FFT
+    QD_FIXED(0, 1, 128, 128, 32, 200, 1, 9, true, 4, "cfg3p"),
+    QD_FIXED(0, 2, 128, 128, 32, 200, 1, 9, true, 4, "cfg3p"),
+    // README.md:90-94 / configs[2]  "lowpass -power 200 -decimate 32 200000 | sparkfft -width 64 -stride 16"
+    QD_FIXED(0, 1, 64, 16, 32, 400, 4, 9, true, 4, "fsk5"),
+    QD_FIXED(0, 2, 64, 16, 32, 400, 4, 9, true, 4, "fsk5"),
+#ifndef QD_DEV_FAST
+    QD_FIXED(1, 1, 64, 16, 32, 400, 4, 5, true, 4, "cfg3"),
+    QD_FIXED(1, 2, 64, 16, 32, 400, 4, 5, true, 4, "cfg3"),
+#endif
+    // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
+    QD_FIXED(0, 0, 1024, 1024, 8, 512, 1, 4, false, 4, "cfg4"),
+};
+
+const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t D, uint32_t T) {
+    if (getenv("QD_NO_FIXED")) return nullptr;       // tests compare the specialised and generic kernels
+    for (const FixedEntry &e : kFixed)
+        if (e.fmt == fmt && e.nco == nco && e.W == W && e.S == S && e.D == D && e.T == T) return &e;
     return nullptr;
 }
 
@@ -242,8 +295,9 @@ struct qd_plan {
     FftLayout fft;
     float2 *tw_d = nullptr;
     Geometry geo;
-    chain_fn fn = nullptr;
-    int wg_per_cu = 1, n_cu = 256;
+    chain_fn fn = nullptr, fn_unaligned = nullptr;
+    const FixedEntry *fixed = nullptr;
+    int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0;
     // NCO tables
     double2 *jtab_d = nullptr;
     RowBase *rowtab_d = nullptr;
@@ -301,19 +355,17 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     ChainParams P{};
     P.src = static_cast<const uint8_t *>(src_d);
     P.src_first = src_first; P.src_count = src_count;
-    P.first_window = first_window; P.n_windows = n_windows; P.out_window0 = out_window0;
-    P.W = p->W; P.logW = p->logW; P.S = p->S; P.D = p->D; P.T = p->T; P.c = p->T - p->T / 2;
+    P.out_window0 = out_window0;
+    P.W = p->W; P.logW = p->logW; P.S = p->S; P.D = p->D; P.T = p->T;
+    const uint32_t c = p->T - p->T / 2;
     P.G = p->geo.G; P.Dp = p->geo.Dp;
     P.dmagic = p->D > 1 ? (uint32_t)((1ull << 32) / p->D + 1) : 0;
-    P.a0 = P.c / p->D; P.b0 = P.c % p->D;
+    P.dshift = is_pow2(p->D) ? ilog2(p->D) : 0xffffffffu;
+    P.a0 = c / p->D; P.b0 = c % p->D;
     uint32_t tfast = p->D + p->T / 2;
     P.T_fast = tfast < p->T ? tfast : p->T;
-    P.a1 = (P.c + P.T_fast) / p->D; P.b1 = (P.c + P.T_fast) % p->D;
+    P.a1 = (c + P.T_fast) / p->D; P.b1 = (c + P.T_fast) % p->D;
     P.base_len = p->fft.base_len; P.log_base = p->fft.log_base; P.layers = p->fft.layers;
-    const int vec_bytes = spl * bps;
-    P.vec_ok = ((reinterpret_cast<uintptr_t>(src_d) % vec_bytes) == 0 && (src_first % spl) == 0) ? 1 : 0;
-    // |place| = n*|ratio|; second-order NCO term matters once ulp(place)^2/2 approaches 1e-16
-    P.second_order = (std::fabs(p->ratio) * (double)need1 > 67108864.0) ? 1 : 0;
     P.epi = (uint32_t)p->d.epilogue;
     P.lds_raw_elems = p->geo.lds_raw_elems;
     P.rmin = p->d.has_range ? p->d.range_min : 0.08f;     // src/fft.rs:22-23
@@ -324,16 +376,37 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     P.rowtab = p->rowtab_d; P.rowtab_row0 = p->rowtab_row0;
     P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
     P.out = out_d;
+    if (const char *e = getenv("QD_DEBUG_SKIP")) P.dbg = (uint32_t)atoi(e);   // timing-only ablation, never set in tests/bench
 
-    uint64_t n_tiles = (n_windows + P.G - 1) / P.G;
+    // The aligned kernels issue whole-vector loads: the slab must start on a vector boundary and a
+    // window whose last vector would straddle the slab end goes to the per-sample kernel instead.
+    const int vec_bytes = spl * bps;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(src_d) % vec_bytes) == 0 && (src_first % spl) == 0 &&
+                        src_count * (uint64_t)bps >= (uint64_t)vec_bytes;
+    uint64_t n_aligned = 0;
+    if (vec_ok) {
+        // windows [first_window, first_window + n_aligned): need-end rounded up to a vector fits in the slab
+        const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
+        const uint64_t usable = (src_count / spl) * spl + src_first;     // end of the last whole vector
+        n_aligned = n_windows;
+        while (n_aligned > 0 && (first_window + n_aligned - 1) * step + rpw > usable) --n_aligned;
+    }
     uint64_t cap = (uint64_t)p->n_cu * p->wg_per_cu;
-    uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
+    if (const char *e = getenv("QD_WG_PER_CU")) cap = (uint64_t)p->n_cu * (uint64_t)atoi(e);   // tuning knob
     if (p->timing) {
         if (!p->ev_made) { HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1)); p->ev_made = true; }
         HIPCHK(hipEventRecord(p->ev0, st));
     }
-    hipLaunchKernelGGL(p->fn, dim3(grid), dim3(kThreads), p->geo.lds_bytes, st, P);
-    HIPCHK(hipGetLastError());
+    for (int part = 0; part < 2; ++part) {
+        const uint64_t w_begin = part == 0 ? first_window : first_window + n_aligned;
+        const uint64_t w_count = part == 0 ? n_aligned : n_windows - n_aligned;
+        if (w_count == 0) continue;
+        P.first_window = w_begin; P.n_windows = w_count;
+        const uint64_t n_tiles = (w_count + P.G - 1) / P.G;
+        const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
+        hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(kThreads), p->geo.lds_bytes, st, P);
+        HIPCHK(hipGetLastError());
+    }
     if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
     return QD_OK;
 }
@@ -403,29 +476,44 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     else p->n_windows = lim == 0 ? 0 : (lim - 1) / d.stride + 1;                        // src/fft.rs:28,65
     p->ratio = p->has_shift ? qd_shift_ratio(d.shift_hz, d.sample_rate) : 0.0;
 
-    // tile geometry
+    // |place| = n*|ratio| over the whole stream decides the NCO order once per plan: the second-order
+    // term e^2/2 (e ~ ulp(place)) matters once it approaches 1e-16, i.e. |place| > 2^26
+    p->nco = !p->has_shift ? 0 : ((std::fabs(p->ratio) * (double)d.n_samples > 67108864.0) ? 2 : 1);
+    if (const char *e = getenv("QD_NCO_ORDER")) { int v = atoi(e); if (p->has_shift && (v == 1 || v == 2)) p->nco = v; }
+
+    // tile geometry: a shape-specialised kernel dictates G; otherwise pick G for LDS / lane use
     uint32_t G = 1, raw_elems = 0;
-    if (lds_for(1, p->W, p->S, p->D, p->T, &raw_elems) > kLdsMax) {
+    if (lds_for(1, p->W, p->S, p->D, p->T, &raw_elems) > kLdsMax)
         return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
                     (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
+    p->fixed = p->has_fir ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
+    if (p->fixed) {
+        G = p->fixed->G;
+    } else {
+        while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 40 * 1024) G *= 2;
+        while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 36 * 1024) G *= 2;
+        if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
     }
-    while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 40 * 1024) G *= 2;
-    while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 36 * 1024) G *= 2;
-    if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
     p->geo.G = G;
     p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, p->T, &raw_elems);
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
-    if ((uint64_t)raw_elems * p->D >= (1ull << 32)) { return fail(QD_ERR_UNSUPPORTED, "tile too large"); }
+    if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
 
-    p->fn = pick_kernel(d.format, p->has_shift, p->has_fir);
+    p->fn = p->fixed ? p->fixed->fn : pick_generic(d.format, p->nco, p->has_fir, true);
+    p->fn_unaligned = pick_generic(d.format, p->nco, p->has_fir, false);
+    if (!p->fn || !p->fn_unaligned) return fail(QD_ERR_UNSUPPORTED, "no kernel built for this format (QD_DEV_FAST build?)");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->n_cu = prop.multiProcessorCount;
     int by_lds = (int)(kLdsMax / p->geo.lds_bytes);
-    p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p->fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)p->geo.lds_bytes);
-    if (e != hipSuccess) { return fail(QD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS %zu): %s", p->geo.lds_bytes, hipGetErrorString(e)); }
+    p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
+    if (p->fixed && p->wg_per_cu > p->fixed->wg_per_cu) p->wg_per_cu = p->fixed->wg_per_cu;
+    for (chain_fn f : {p->fn, p->fn_unaligned}) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)p->geo.lds_bytes);
+        if (e != hipSuccess)
+            return fail(QD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS %zu): %s", p->geo.lds_bytes, hipGetErrorString(e));
+    }
 
     // constant tables
     p->fft = fft_layout(d.width);

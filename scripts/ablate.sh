@@ -1,0 +1,5 @@
+#!/bin/bash
+# timing-only ablation of the chain kernel phases (results are wrong by construction)
+for skip in 0 1 2 3 4 8 7 15; do
+  QD_DEBUG_SKIP=$skip python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('skip=$skip', 'kernel_ms=%.4f'%d['roofline']['kernel_ms'], 'GB/s=%.0f'%d['roofline']['achieved'])"
+done
