@@ -123,6 +123,7 @@ struct TileGeo {            // everything wave-uniform
     uint64_t w0, n_start;
     uint64_t r0;            // first absolute row touching the tile
     int64_t row0_off;       // byte offset of row r0 inside the slab (may be negative)
+    int32_t slab_lo0, slab_hi0;   // legal byte offsets relative to row r0 (slab bounds, saturated to +-2^30)
     uint32_t n_rows;        // rows touching the tile
     uint32_t g_cnt, tile_raw;
     int32_t rel0;           // r0*ROW - n_start  (in (-ROW, 0])
@@ -144,6 +145,11 @@ __device__ __forceinline__ TileGeo tile_geo(const ChainParams &P, const GeoT &ge
     g.rel0 = (int32_t)(int64_t)(g.r0 * ROW - g.n_start);
     g.n_rows = (uint32_t)((g.tile_raw - g.rel0 + ROW - 1) / ROW);
     g.row0_off = ((int64_t)(g.r0 * ROW) - (int64_t)P.src_first) * BPS;
+    constexpr int64_t BIG = 1ll << 30;
+    constexpr int32_t VECB = FmtTraits<FMT>::SPL * BPS;
+    int64_t lo = -g.row0_off, hi = (int64_t)P.src_count * BPS - VECB - g.row0_off;
+    g.slab_lo0 = (int32_t)(lo < -BIG ? -BIG : (lo > BIG ? BIG : lo));
+    g.slab_hi0 = (int32_t)(hi < -BIG ? -BIG : (hi > BIG ? BIG : hi));
     return g;
 }
 
@@ -162,13 +168,21 @@ __device__ __forceinline__ typename FmtTraits<FMT>::Vec fetch_row(const ChainPar
     constexpr int32_t ROWB = kThreads * SPL * BPS, VECB = SPL * BPS;
     if constexpr (ALIGNED) {
         const int64_t row_off = g.row0_off + (int64_t)i * ROWB;                                    // uniform
-        const int64_t hi = (int64_t)P.src_count * BPS - VECB;                                      // last legal offset
-        int64_t lo_rel = -row_off, hi_rel = hi - row_off;                                          // uniform, clamp to i32
+        // Legal lane offsets relative to this row (all 32-bit, wave-uniform): inside the slab AND
+        // inside the tile, so lanes past the tile's edge collapse onto its first / last needed
+        // vector (one cache line instead of a row of never-used bytes).
+        constexpr int32_t LOGV = FMT == 0 ? 4 : (FMT == 3 ? 4 : 3);                                // log2(VECB)
+        const int32_t rel_i = g.rel0 + (int32_t)(i * (kThreads * SPL));                            // row start - tile start
+        const int32_t tlo = ((-rel_i * BPS) >> LOGV) << LOGV;                                      // vector holding the first tile byte
+        const int32_t thi = (((-rel_i + (int32_t)g.tile_raw) * BPS - 1) >> LOGV) << LOGV;          // ... the last tile byte
+        int32_t lo_rel = g.slab_lo0 - (int32_t)(i * ROWB), hi_rel = g.slab_hi0 - (int32_t)(i * ROWB);
+        lo_rel = lo_rel > tlo ? lo_rel : tlo;
+        hi_rel = hi_rel < thi ? hi_rel : thi;
         lo_rel = lo_rel < 0 ? 0 : (lo_rel > ROWB ? ROWB : lo_rel);
         hi_rel = hi_rel > ROWB ? ROWB : (hi_rel < -ROWB ? -ROWB : hi_rel);
         int32_t t = (int32_t)(tid * VECB);
-        t = t < (int32_t)lo_rel ? (int32_t)lo_rel : t;
-        t = t > (int32_t)hi_rel ? (int32_t)hi_rel : t;
+        t = t < lo_rel ? lo_rel : t;
+        t = t > hi_rel ? hi_rel : t;
         const uint8_t *rowp = P.src + row_off;                                                     // uniform base
         return *reinterpret_cast<const Vec *>(rowp + t);
     } else {
@@ -342,7 +356,8 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
     float2 *fb = raw + geo.lds_raw_elems;
-    float *lut = reinterpret_cast<float *>(fb + (size_t)geo.G * geo.W);
+    float2 *twl = fb + (size_t)geo.G * geo.W;                 // radix-4 layer twiddles (< W entries), staged once
+    float *lut = reinterpret_cast<float *>(twl + geo.W);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
@@ -363,7 +378,13 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
         }
     }
     const uint32_t lane_pad = pad_index(geo, tid * SPL);      // LDS element of this lane's first sample in a row
-    if constexpr (FMT == 1 || FMT == 2) __syncthreads();
+    // Stage the layer twiddles in LDS: phases 2-4 then issue no vector-memory loads, so nothing in
+    // them has to wait behind the next tile's prefetch (vmcnt retires in order).
+    {
+        const uint32_t n_tw = W - geo.base_len;               // 3*(base + 4*base + ...) = W - base
+        for (uint32_t i = tid; i < n_tw; i += kThreads) twl[i] = P.tw[i];
+    }
+    __syncthreads();
 
     const uint64_t n_tiles = (P.n_windows + geo.G - 1) / geo.G;
 
@@ -485,7 +506,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                 }
             }
             uint32_t cols = base, log_cols = geo.log_base;
-            const float2 *tw = P.tw;
+            const float2 *tw = twl;
             for (uint32_t layer = 0; layer < geo.layers; ++layer) {
                 __syncthreads();
                 const uint32_t n_bf = (g_cnt << logW) >> 2;   // W/4 butterflies per window

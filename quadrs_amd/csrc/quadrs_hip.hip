@@ -274,7 +274,7 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     if (elems < min_elems) elems = min_elems;
     elems = (elems + 1) & ~1ull;                      // keep fb 16-byte aligned
     if (raw_elems) *raw_elems = (uint32_t)elems;
-    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + 256 * 4);
+    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + W * 8 + 256 * 4);   // raw tile + FFT buffer + twiddles + 8-bit LUT
 }
 
 constexpr size_t kLdsMax = 160 * 1024;

@@ -1,0 +1,35 @@
+"""Turns a scripts/profile_round.sh output directory into the small files kept under profiles/."""
+import collections, csv, glob, json, os, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+args = sys.argv[3:]
+workload = "cfg2"
+if "--workload" in args:
+    workload = args[args.index("--workload") + 1]
+res = {"tag": tag, "workload": workload, "bench_args": args}
+ks = glob.glob(f"{out}/kt/*/*kernel_stats.csv")
+rows = list(csv.DictReader(open(ks[0])))
+chain = [r for r in rows if "k_chain" in r["Name"]]
+res["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in chain]
+pmc = {}
+for d in ("fetch", "write", "sq", "sq2"):
+    f = glob.glob(f"{out}/{d}/*/*counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if "k_chain" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc[k] = sum(v) / len(v)
+res["pmc_mean_per_launch"] = pmc
+# MI355X_MICROARCH.md §HBM: FETCH_SIZE (KiB) reports exactly half of a 16 B/lane streaming read on gfx950
+# -> double it; WRITE_SIZE (KiB) is exact for 16 B/lane... our 4 B/lane output stores are a small term.
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    res["hbm_bytes_per_launch"] = 2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024
+    res["hbm_note"] = "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction for wide coalesced reads)"
+os.makedirs("gpurun_out/profiles_out", exist_ok=True)
+json.dump(res, open(f"gpurun_out/profiles_out/{tag}.json", "w"), indent=1)
+with open(f"gpurun_out/profiles_out/{tag}_kernel_stats.csv", "w") as f:
+    f.write(open(ks[0]).read())
+print(json.dumps(res, indent=1)[:1500])
