@@ -32,13 +32,30 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
-        return OUT
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-o", OUT] + SRC
+CLI_SRC = os.path.join(HERE, "cli", "quadrs_hip_cli.cpp")
+CLI_OUT = os.path.join(HERE, "quadrs-hip")
+
+
+def build_cli(force=False, verbose=False):
+    """The C++ host driver (reference CLI grammar + operator chain over the C ABI)."""
+    if not force and os.path.exists(CLI_OUT) and os.path.getmtime(CLI_OUT) >= max(
+            os.path.getmtime(CLI_SRC), os.path.getmtime(OUT), os.path.getmtime(DEPS[-1])):
+        return CLI_OUT
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", CLI_OUT, CLI_SRC,
+           "-L", HERE, "-lquadrs_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    return CLI_OUT
+
+
+def build(force=False, verbose=False, extra=()):
+    if force or needs_build():
+        cmd = [hipcc()] + FLAGS + list(extra) + ["-o", OUT] + SRC
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    build_cli(force=force, verbose=verbose)
     return OUT
 
 
