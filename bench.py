@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--samples-log2", type=int, default=None, help="override samples per GPU (2^k); rehearsals only")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0, halo staged through the host")
     args = ap.parse_args()
 
     import torch
@@ -124,15 +127,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
 
-    cfg = WORKLOADS[args.workload]
+    cfg = dict(WORKLOADS[args.workload])
+    if args.samples_log2 is not None:
+        cfg["n"] = 1 << args.samples_log2
     fmt, bps = cfg["fmt"], BPS[cfg["fmt"]]
     n_total = cfg["n"] * world                       # weak scaling: one slab per GPU
     plan = Q.Plan(fmt, cfg["sr"], n_total, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
@@ -142,7 +151,12 @@ def main():
 
     own = synth_slab(torch, fmt, me.own_first, me.own_count, 0x5EED0002 + rank, device)
     own_u8 = own.view(torch.uint8).reshape(-1)
-    slab = SH.exchange(own_u8, shards, rank, bps, dist) if world > 1 else own_u8    # halo over RCCL/xGMI, once
+    if world == 1:
+        slab = own_u8
+    elif args.rehearse:
+        slab = SH.exchange(own_u8.cpu(), shards, rank, bps, dist).to(device)         # gloo: staged through the host
+    else:
+        slab = SH.exchange(own_u8, shards, rank, bps, dist)                          # halo over RCCL/xGMI, once
     del own
     nw = me.w1 - me.w0
     out = torch.empty(nw, cfg["W"], dtype=torch.float32, device=device)
@@ -168,7 +182,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -185,7 +199,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload:
+                if tj.get("workload") == args.workload and args.samples_log2 is None:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libquadrs_hip.so")
+LIB_PATH = os.environ.get("QD_LIB_PATH") or os.path.join(_HERE, "libquadrs_hip.so")   # QD_LIB_PATH: diagnostic builds
 
 OK, ERR_INVALID, ERR_PANIC, ERR_SHORT, ERR_HIP, ERR_UNSUPPORTED = range(6)
 FMT_CF32, FMT_CS8, FMT_CU8, FMT_CS16 = 0, 1, 2, 3

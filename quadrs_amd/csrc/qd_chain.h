@@ -26,6 +26,21 @@
 
 namespace qd {
 
+// In-kernel phase stamps (cdna_hip_programming.md §7): diagnostic build only, never in the shipped .so.
+#ifdef QD_STAMP
+#define QD_STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned st_tiles = 0;
+#define QD_STAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); } while (0)
+#define QD_STAMP_AT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 0) atomicAdd(&P.stamps[32], (unsigned long long)st_tiles); } } while (0)
+#define QD_STAMP_TILE() do { ++st_tiles; } while (0)
+#else
+#define QD_STAMP_DECL
+#define QD_STAMP_START()
+#define QD_STAMP_AT(k)
+#define QD_STAMP_FLUSH()
+#define QD_STAMP_TILE()
+#endif
+
 constexpr int kThreads = 256;
 
 // Wave-uniform read-only tables (taps, row bases) are read through the constant address space
@@ -60,6 +75,7 @@ struct ChainParams {
     float2 tw16_1, tw16_2, tw16_3;
     uint32_t epi;              // qd_epilogue
     uint32_t dbg;              // timing-only ablation bits (QD_DEBUG_SKIP); 0 in every real run
+    unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
     // ---- geometry (only DynGeo reads these; FixedGeo has them as constants)
     uint32_t W, logW, S, D, T, G;
     uint32_t Dp;               // LDS row pitch: D + 1 if D even else D
@@ -252,11 +268,10 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
     }
     if constexpr (NCO != 0) {
         if (!(P.dbg & 1)) {
+            float2 m[SPL];
+            nco_mul_n<NCO == 2, SPL>(rb, lr, P.ratio, m);          // the SPL f64 chains issued interleaved
 #pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                float2 m = nco_mul<NCO == 2>(rb, lr[u], P.ratio);
-                x[u] = cmul(x[u], m);                              // buf[i] *= mul (src/shift.rs:51)
-            }
+            for (int u = 0; u < SPL; ++u) x[u] = cmul(x[u], m[u]);   // buf[i] *= mul (src/shift.rs:51)
         }
     }
     // Additive addressing: rel is a multiple of D (n_start and ROW both are) and SPL divides D, so
@@ -299,21 +314,48 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
     const uint32_t D = geo.D, Dp = geo.Dp;
     const uint32_t n = j1 - j0;                       // taps to do
     const uint32_t n_rows = (b + n + D - 1) / D;      // LDS rows touched
-    const_f32_p h = (const_f32_p)(uintptr_t)(taps + j0);
+    const float *h = taps + j0;                      // LDS, same address in every lane: broadcast reads
     if constexpr (GeoT::kFixed) {
+        // Fully unrolled: every bound is a constant, LDS offsets are immediates.
+        (void)n_rows;
+        auto lds_index = [&](uint32_t jj) -> uint32_t { const uint32_t t = b + jj; return (t / D) * Dp + (t % D); };
+        if (n < 64) {
+            // short filters: let the scheduler interleave reads and the accumulate chain
 #pragma unroll
-        for (uint32_t a = 0; a < n_rows; ++a) {
-            const uint32_t bs = a == 0 ? b : 0;
-            const uint32_t be = (b + n - a * D) < D ? (b + n - a * D) : D;
-#pragma unroll
-            for (uint32_t bb = bs; bb < be; ++bb) {
-                const uint32_t jj = a * D + bb - b;   // tap index relative to j0
-                float2 x = rowp[a * Dp + bb];
-                float hh = h[jj];
-                if (!PRED || (j0 + jj) < jmax) {
+            for (uint32_t i = 0; i < n; ++i) {
+                float2 x = rowp[lds_index(i)];
+                float hh = h[i];
+                if (!PRED || (j0 + i) < jmax) {
                     accr = accr + x.x * hh;           // Complex<f32> * f32, then +=  (src/filter.rs:119)
                     acci = acci + x.y * hh;
                 }
+            }
+        } else {
+            // long filters, software-pipelined by hand: the LDS reads of block k+1 (8 taps: samples +
+            // tap values) are issued before block k is consumed, so the dependent multiply/accumulate
+            // chain does not stall on LDS latency after every pair.
+            constexpr uint32_t B = 8;
+            float2 xa[B]; float ha[B];
+#pragma unroll
+            for (uint32_t i = 0; i < B; ++i) if (i < n) { xa[i] = rowp[lds_index(i)]; ha[i] = h[i]; }
+#pragma unroll
+            for (uint32_t base = 0; base < n; base += B) {
+                float2 xb[B]; float hb[B];
+#pragma unroll
+                for (uint32_t i = 0; i < B; ++i) if (base + B + i < n) { xb[i] = rowp[lds_index(base + B + i)]; hb[i] = h[base + B + i]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (uint32_t i = 0; i < B; ++i) {
+                    if (base + i < n) {
+                        if (!PRED || (j0 + base + i) < jmax) {
+                            accr = accr + xa[i].x * ha[i];
+                            acci = acci + xa[i].y * ha[i];
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (uint32_t i = 0; i < B; ++i) { xa[i] = xb[i]; ha[i] = hb[i]; }
             }
         }
     } else {
@@ -357,7 +399,8 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
     float2 *raw = reinterpret_cast<float2 *>(smem);
     float2 *fb = raw + geo.lds_raw_elems;
     float2 *twl = fb + (size_t)geo.G * geo.W;                 // radix-4 layer twiddles (< W entries), staged once
-    float *lut = reinterpret_cast<float *>(twl + geo.W);
+    float *tapl = reinterpret_cast<float *>(twl + geo.W);     // FIR taps (T floats, padded to a multiple of 4)
+    float *lut = tapl + ((geo.T + 3) & ~3u);                  // 8-bit unpack table
 
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
@@ -383,6 +426,10 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
     {
         const uint32_t n_tw = W - geo.base_len;               // 3*(base + 4*base + ...) = W - base
         for (uint32_t i = tid; i < n_tw; i += kThreads) twl[i] = P.tw[i];
+        // ... and the taps: the FIR loop then contains LDS reads only, so its waits are counted
+        // lgkmcnt(N) instead of a full drain per batch (scalar loads share that counter and return
+        // out of order, which forces lgkmcnt(0)).
+        for (uint32_t i = tid; i < T; i += kThreads) tapl[i] = P.taps[i];
     }
     __syncthreads();
 
@@ -398,6 +445,8 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
         for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, ALIGNED>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
     }
 
+    QD_STAMP_DECL
+    QD_STAMP_START();
     while (tg.valid) {
         const uint64_t w0 = tg.w0;
         const uint32_t g_cnt = tg.g_cnt;
@@ -406,13 +455,17 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
         if constexpr (WHOLE) {
             TileGeo ng = tile_geo<FMT>(P, geo, tile + gridDim.x, n_tiles);
             if (!ng.valid) ng = tg;                  // last tile of this workgroup: harmless re-loads
+            RowBase rb_next{};
+            if constexpr (HAS_SHIFT) rb_next = load_rowbase(P, tg.r0);
 #pragma unroll
             for (int i = 0; i < RCH; ++i) {
                 const Vec v = pf[i];
                 pf[i] = fetch_row<FMT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
                 if ((uint32_t)i < tg.n_rows) {
-                    RowBase rb{};
-                    if constexpr (HAS_SHIFT) rb = load_rowbase(P, tg.r0 + i);
+                    const RowBase rb = rb_next;
+                    if constexpr (HAS_SHIFT) {           // scalar load for the next row while this one computes
+                        if ((uint32_t)i + 1 < tg.n_rows) rb_next = load_rowbase(P, tg.r0 + i + 1);
+                    }
                     process_row_any<FMT, NCO>(P, geo, tg, i, tid, v, rb, lr, lane_pad, lut, raw);
                 }
             }
@@ -441,7 +494,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                     if (r + i < tg.n_rows) process_row_any<FMT, NCO>(P, geo, tg, r + i, tid, cur[i], rb[i], lr, lane_pad, lut, raw);
             }
         }
+        QD_STAMP_AT(0);
         __syncthreads();
+        QD_STAMP_AT(1);
 
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
         const uint32_t n_out = g_cnt << logW;
@@ -456,11 +511,11 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                 if (jmax > T) jmax = T;
                 const float2 *rowp = raw + (size_t)(q + geo.a0) * Dp;
                 if (geo.T_fast == T || __all(jmax == T)) {
-                    fir_span<false>(geo, rowp, geo.b0, 0, T, T, P.taps, accr, acci);
+                    fir_span<false>(geo, rowp, geo.b0, 0, T, T, tapl, accr, acci);
                 } else {
-                    fir_span<false>(geo, rowp, geo.b0, 0, geo.T_fast, T, P.taps, accr, acci);
+                    fir_span<false>(geo, rowp, geo.b0, 0, geo.T_fast, T, tapl, accr, acci);
                     const float2 *rowp1 = raw + (size_t)(q + geo.a1) * Dp;
-                    fir_span<true>(geo, rowp1, geo.b1, geo.T_fast, T, jmax, P.taps, accr, acci);
+                    fir_span<true>(geo, rowp1, geo.b1, geo.T_fast, T, jmax, tapl, accr, acci);
                 }
             } else {
                 float2 v = raw[HAS_FIR ? q * Dp : q];
@@ -471,7 +526,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
             const uint32_t pos = yy + (rev4(xx, geo.layers) << geo.log_base);
             fb[(g << logW) + pos] = make_float2(accr, acci);
         }
+        QD_STAMP_AT(2);
         __syncthreads();
+        QD_STAMP_AT(3);
 
         // ---------------- phase 3: FFT (rustfft Radix4: base butterflies, then radix-4 layers)
         if (!(P.dbg & 4)) {
@@ -526,7 +583,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                 log_cols += 2;
             }
         }
+        QD_STAMP_AT(4);
         __syncthreads();
+        QD_STAMP_AT(5);
 
         // ---------------- phase 4: fftshift + norm + epilogue (out index is tile base + o: coalesced)
         const uint64_t wrel = w0 - P.out_window0;
@@ -552,10 +611,14 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                 else outb[o] = glyph_code(nm, P.rmin, P.rmax);
             }
         }
+        QD_STAMP_AT(6);
         __syncthreads();
+        QD_STAMP_AT(7);
+        QD_STAMP_TILE();
         tile += gridDim.x;
         tg = tile_geo<FMT>(P, geo, tile, n_tiles);
     }
+    QD_STAMP_FLUSH();
 }
 
 }  // namespace qd

@@ -165,4 +165,71 @@ __device__ __forceinline__ float2 nco_mul(const RowBase &rb, const LaneRot &lr, 
     return make_float2((float)c, (float)s);
 }
 
+// The same arithmetic for the N samples a lane owns, written step-by-step across the samples so
+// that the N independent f64 dependency chains are issued interleaved (the chain is ~10 ops deep;
+// issued one sample after the other the wave stalls on every result).
+template <bool SECOND_ORDER, int N>
+__device__ __forceinline__ void nco_mul_n(const RowBase &rb, const LaneRot *lr, double ratio, float2 *m) {
+    double e[N], cd[N], sd[N], c[N], s[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) e[u] = rb.nf + lr[u].jf;
+#pragma unroll
+    for (int u = 0; u < N; ++u) e[u] = e[u] * ratio;
+#pragma unroll
+    for (int u = 0; u < N; ++u) e[u] = e[u] - rb.theta;
+#pragma unroll
+    for (int u = 0; u < N; ++u) e[u] = e[u] - lr[u].tj;
+    if constexpr (SECOND_ORDER) {
+        double h[N], uu[N], vv[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) h[u] = 0.5 * e[u];
+#pragma unroll
+        for (int u = 0; u < N; ++u) { uu[u] = __builtin_fma(h[u], lr[u].c, lr[u].s); vv[u] = __builtin_fma(-h[u], lr[u].s, lr[u].c); }
+#pragma unroll
+        for (int u = 0; u < N; ++u) { cd[u] = __builtin_fma(-e[u], uu[u], lr[u].c); sd[u] = __builtin_fma(e[u], vv[u], lr[u].s); }
+    } else {
+#pragma unroll
+        for (int u = 0; u < N; ++u) { cd[u] = __builtin_fma(-e[u], lr[u].s, lr[u].c); sd[u] = __builtin_fma(e[u], lr[u].c, lr[u].s); }
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) { c[u] = rb.c * cd[u]; s[u] = rb.s * cd[u]; }
+#pragma unroll
+    for (int u = 0; u < N; ++u) { c[u] = __builtin_fma(-rb.s, sd[u], c[u]); s[u] = __builtin_fma(rb.c, sd[u], s[u]); }
+#pragma unroll
+    for (int u = 0; u < N; ++u) m[u] = make_float2((float)c[u], (float)s[u]);
+}
+
+// NCO multipliers for M samples that may sit in different rows: per-sample row constants.
+// Same arithmetic as nco_mul, interleaved across the M independent chains.
+template <bool SECOND_ORDER, int M>
+__device__ __forceinline__ void nco_mul_m(const RowBase *const *rb, const LaneRot *const *lr, double ratio, float2 *m) {
+    double e[M], cd[M], sd[M], c[M], s[M];
+#pragma unroll
+    for (int u = 0; u < M; ++u) e[u] = rb[u]->nf + lr[u]->jf;
+#pragma unroll
+    for (int u = 0; u < M; ++u) e[u] = e[u] * ratio;
+#pragma unroll
+    for (int u = 0; u < M; ++u) e[u] = e[u] - rb[u]->theta;
+#pragma unroll
+    for (int u = 0; u < M; ++u) e[u] = e[u] - lr[u]->tj;
+    if constexpr (SECOND_ORDER) {
+        double h[M], uu[M], vv[M];
+#pragma unroll
+        for (int u = 0; u < M; ++u) h[u] = 0.5 * e[u];
+#pragma unroll
+        for (int u = 0; u < M; ++u) { uu[u] = __builtin_fma(h[u], lr[u]->c, lr[u]->s); vv[u] = __builtin_fma(-h[u], lr[u]->s, lr[u]->c); }
+#pragma unroll
+        for (int u = 0; u < M; ++u) { cd[u] = __builtin_fma(-e[u], uu[u], lr[u]->c); sd[u] = __builtin_fma(e[u], vv[u], lr[u]->s); }
+    } else {
+#pragma unroll
+        for (int u = 0; u < M; ++u) { cd[u] = __builtin_fma(-e[u], lr[u]->s, lr[u]->c); sd[u] = __builtin_fma(e[u], lr[u]->c, lr[u]->s); }
+    }
+#pragma unroll
+    for (int u = 0; u < M; ++u) { c[u] = rb[u]->c * cd[u]; s[u] = rb[u]->s * cd[u]; }
+#pragma unroll
+    for (int u = 0; u < M; ++u) { c[u] = __builtin_fma(-rb[u]->s, sd[u], c[u]); s[u] = __builtin_fma(rb[u]->c, sd[u], s[u]); }
+#pragma unroll
+    for (int u = 0; u < M; ++u) m[u] = make_float2((float)c[u], (float)s[u]);
+}
+
 }  // namespace qd

@@ -274,7 +274,7 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     if (elems < min_elems) elems = min_elems;
     elems = (elems + 1) & ~1ull;                      // keep fb 16-byte aligned
     if (raw_elems) *raw_elems = (uint32_t)elems;
-    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + W * 8 + 256 * 4);   // raw tile + FFT buffer + twiddles + 8-bit LUT
+    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + W * 8 + ((T + 3) & ~3ull) * 4 + 256 * 4);   // raw tile + FFT buffer + twiddles + taps + 8-bit LUT
 }
 
 constexpr size_t kLdsMax = 160 * 1024;
@@ -377,6 +377,12 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
     P.out = out_d;
     if (const char *e = getenv("QD_DEBUG_SKIP")) P.dbg = (uint32_t)atoi(e);   // timing-only ablation, never set in tests/bench
+#ifdef QD_STAMP
+    static unsigned long long *stamps_d = nullptr;
+    if (!stamps_d) { HIPCHK(hipMalloc(&stamps_d, 40 * 8)); }
+    HIPCHK(hipMemsetAsync(stamps_d, 0, 40 * 8, st));
+    P.stamps = stamps_d;
+#endif
 
     // The aligned kernels issue whole-vector loads: the slab must start on a vector boundary and a
     // window whose last vector would straddle the slab end goes to the per-sample kernel instead.
@@ -408,6 +414,24 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         HIPCHK(hipGetLastError());
     }
     if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
+#ifdef QD_STAMP
+    {
+        unsigned long long h[40];
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(h, P.stamps, sizeof h, hipMemcpyDeviceToHost));
+        static const char *names[8] = {"phase1", "bar1", "fir", "bar2", "fft", "bar3", "epilogue", "bar4"};
+        double tiles = (double)h[32];
+        unsigned grid_wgs = (unsigned)(((n_windows + P.G - 1) / P.G) < cap ? ((n_windows + P.G - 1) / P.G) : cap);
+        fprintf(stderr, "[stamps] tiles/launch %.0f (wgs %u): cycles per tile per wave:", tiles, grid_wgs);
+        for (int w = 0; w < 4; ++w) {
+            fprintf(stderr, "\n   wave%d:", w);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s=%.0f", names[k], h[w * 8 + k] / tiles); tot += h[w * 8 + k] / tiles; }
+            fprintf(stderr, "  total=%.0f", tot);
+        }
+        fprintf(stderr, "\n");
+    }
+#endif
     return QD_OK;
 }
 
