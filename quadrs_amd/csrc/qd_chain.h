@@ -308,13 +308,21 @@ __device__ __forceinline__ void process_row_any(const ChainParams &P, const GeoT
 // Taps [j0, j1) for one output; rowp points at the LDS row (of D samples, pitch Dp) holding tap j0
 // at column b.  Control flow is wave-uniform; only rowp and jmax differ per lane.  With FixedGeo
 // all bounds are constants and both loops unroll completely (LDS offsets become immediates).
-template <bool PRED, class GeoT>
+// SNAP (shape-specialised kernels only): the truncated outputs of the reference are
+// prefix sums of the same ascending-j chain, and a lane's jmax can only be T/2 + m*D.  So the wave
+// runs ONE unpredicated chain over all T taps and copies the accumulator aside when the tap index
+// reaches one of those compile-time-known values and equals the lane's jmax — 3 VALU ops per D
+// taps instead of a predicate on every tap past T_fast.
+template <bool PRED, class GeoT, bool SNAP = false>
 __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, uint32_t b, uint32_t j0, uint32_t j1,
                                          uint32_t jmax, const float *__restrict__ taps, float &accr, float &acci) {
     const uint32_t D = geo.D, Dp = geo.Dp;
     const uint32_t n = j1 - j0;                       // taps to do
     const uint32_t n_rows = (b + n + D - 1) / D;      // LDS rows touched
     const float *h = taps + j0;                      // LDS, same address in every lane: broadcast reads
+    float snapr = 0.f, snapi = 0.f;
+    // is tap index jj (absolute, == j0 + relative) a possible jmax?  T/2 + m*D with m >= 1
+    auto is_snap = [&](uint32_t jj) -> bool { return SNAP && jj >= geo.T / 2 + D && jj < geo.T && ((jj - geo.T / 2) % D) == 0; };
     if constexpr (GeoT::kFixed) {
         // Fully unrolled: every bound is a constant, LDS offsets are immediates.
         (void)n_rows;
@@ -325,6 +333,7 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
             for (uint32_t i = 0; i < n; ++i) {
                 float2 x = rowp[lds_index(i)];
                 float hh = h[i];
+                if (is_snap(j0 + i)) { if (jmax == j0 + i) { snapr = accr; snapi = acci; } }
                 if (!PRED || (j0 + i) < jmax) {
                     accr = accr + x.x * hh;           // Complex<f32> * f32, then +=  (src/filter.rs:119)
                     acci = acci + x.y * hh;
@@ -347,6 +356,7 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
 #pragma unroll
                 for (uint32_t i = 0; i < B; ++i) {
                     if (base + i < n) {
+                        if (is_snap(j0 + base + i)) { if (jmax == j0 + base + i) { snapr = accr; snapi = acci; } }
                         if (!PRED || (j0 + base + i) < jmax) {
                             accr = accr + xa[i].x * ha[i];
                             acci = acci + xa[i].y * ha[i];
@@ -358,6 +368,7 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                 for (uint32_t i = 0; i < B; ++i) { xa[i] = xb[i]; ha[i] = hb[i]; }
             }
         }
+        if (SNAP && jmax < geo.T) { accr = snapr; acci = snapi; }
     } else {
         uint32_t j = 0;
         while (j < n) {
@@ -512,6 +523,8 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                 const float2 *rowp = raw + (size_t)(q + geo.a0) * Dp;
                 if (geo.T_fast == T || __all(jmax == T)) {
                     fir_span<false>(geo, rowp, geo.b0, 0, T, T, tapl, accr, acci);
+                } else if constexpr (GeoT::kFixed) {
+                    fir_span<false, GeoT, true>(geo, rowp, geo.b0, 0, T, jmax, tapl, accr, acci);
                 } else {
                     fir_span<false>(geo, rowp, geo.b0, 0, geo.T_fast, T, tapl, accr, acci);
                     const float2 *rowp1 = raw + (size_t)(q + geo.a1) * Dp;
