@@ -65,8 +65,8 @@ int qd_unpack(int fmt, const void *bytes, size_t n_pairs, qd_c32 *out, int mem);
 /* Shift::new's ratio, src/shift.rs:28 (host arithmetic, f64). */
 double qd_shift_ratio(int64_t frequency, uint64_t sample_rate);
 
-/* Shift::read_at's loop, src/shift.rs:48-52: buf[i] *= e^{+i (abs_off+i)*ratio}, in place.
- * n_total = Samples::len() of the stream (sizes the NCO base table; pass 0 if unknown). */
+/* Shift::read_at's loop, src/shift.rs:48-52: buf[i] *= e^{+i (abs_off+i)*ratio}, in place;
+ * abs_off is the absolute index of buf[0] in the stream (the NCO phase depends on it). */
 int qd_shift(qd_c32 *buf, size_t n, uint64_t abs_off, double ratio, int mem);
 
 /* lowpass_filter(cutoff_from_frequency(f, sr) as f32, size), src/filter.rs:29-31,86-105,126-128.
@@ -83,6 +83,16 @@ int qd_lowpass_block(const float *taps, size_t T, uint64_t D, const qd_c32 *raw,
 /* Radix4::new(W, Forward) + process + fftshift + norm for n_fft windows, window i starting
  * at in[i*in_stride] (src/fft.rs:25,32,48-53).  norms: n_fft*W f32. */
 int qd_fft_norm_batch(const qd_c32 *in, size_t W, size_t n_fft, size_t in_stride, float *norms, int mem);
+
+/* take_fft, src/ffts.rs:18-85 (the spectrogram rows of the egui front end): output_len rows at
+ * sample start + round(step*i), step = (end-start)/output_len in f64; optional Blackman-Harris
+ * window (windowing 1; src/ffts.rs:110-119, host f32 arithmetic like the reference); forward FFT;
+ * fftshifted norms into rows[output_len*W].  `in` holds samples [in_first, in_first+n_in) of the
+ * cf32 Samples being viewed, whose len() is samples_len.  has_slice 0 => (0, len - W) (:27-30).
+ * Power-of-two W only: the reference's FftPlanner also takes other lengths (not built).
+ * QD_ERR_PANIC / QD_ERR_INVALID mirror the asserts / ensure! at :32-48. */
+int qd_take_fft(const qd_c32 *in, uint64_t in_first, size_t n_in, uint64_t samples_len, int has_slice,
+                uint64_t start, uint64_t end, size_t W, int windowing, size_t output_len, float *rows, int mem);
 
 /* ------------------------------------------------------------------ coarse-grained plan */
 

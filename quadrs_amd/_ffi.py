@@ -16,7 +16,7 @@ SYMBOLS = [
     "qd_last_error", "qd_version", "qd_device_count", "qd_set_device", "qd_pair_bytes", "qd_unpack",
     "qd_shift_ratio", "qd_shift", "qd_lowpass_design", "qd_lowpass_block", "qd_fft_norm_batch",
     "qd_plan_create", "qd_plan_destroy", "qd_plan_get_info", "qd_plan_get_taps", "qd_plan_src_range",
-    "qd_plan_run", "qd_plan_set_timing", "qd_plan_last_kernel_ms", "qd_gen",
+    "qd_plan_run", "qd_plan_set_timing", "qd_plan_last_kernel_ms", "qd_gen", "qd_take_fft",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
             "qd_plan_set_timing": (i32, [vp, i32]),
             "qd_plan_last_kernel_ms": (i32, [vp, C.POINTER(f32)]),
             "qd_gen": (i32, [vp, sz, u64, u64, sz, vp, i32]),
+            "qd_take_fft": (i32, [vp, u64, sz, u64, i32, u64, u64, sz, i32, sz, vp, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -76,6 +76,8 @@ struct ChainParams {
     uint32_t epi;              // qd_epilogue
     uint32_t dbg;              // timing-only ablation bits (QD_DEBUG_SKIP); 0 in every real run
     unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
+    const uint64_t *row_offsets; // take_fft (src/ffts.rs:59-60): window w starts at row_offsets[w] (generic kernels, G = 1)
+    const float *window;         // take_fft windowing (src/ffts.rs:64-68): sample k of a window is scaled by window[k]
     // ---- geometry (only DynGeo reads these; FixedGeo has them as constants)
     uint32_t W, logW, S, D, T, G;
     uint32_t Dp;               // LDS row pitch: D + 1 if D even else D
@@ -104,9 +106,10 @@ constexpr uint32_t ct_raw_elems(uint32_t W, uint32_t S, uint32_t D, uint32_t T, 
     return (elems + 1) & ~1u;
 }
 
-template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_>
+template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8>
 struct FixedGeo {
     static constexpr bool kFixed = true;
+    static constexpr uint32_t kFirBlock = FIRB_;   // taps per software-pipelined FIR block (register budget knob)
     __device__ __forceinline__ explicit FixedGeo(const ChainParams &) {}
     static constexpr uint32_t W = W_, S = S_, D = D_, T = T_, G = G_;
     static constexpr uint32_t logW = ct_log2(W_);
@@ -146,9 +149,9 @@ struct TileGeo {            // everything wave-uniform
     bool valid;
 };
 
-template <int FMT, class GeoT>
+template <int FMT, int NT, class GeoT>
 __device__ __forceinline__ TileGeo tile_geo(const ChainParams &P, const GeoT &geo, uint64_t tile, uint64_t n_tiles) {
-    constexpr uint32_t ROW = kThreads * FmtTraits<FMT>::SPL;
+    constexpr uint32_t ROW = NT * FmtTraits<FMT>::SPL;
     constexpr int BPS = FmtTraits<FMT>::BPS;
     TileGeo g;
     g.valid = tile < n_tiles;
@@ -156,6 +159,9 @@ __device__ __forceinline__ TileGeo tile_geo(const ChainParams &P, const GeoT &ge
     const uint64_t left = P.first_window + P.n_windows - g.w0;
     g.g_cnt = (!g.valid) ? 0u : (left < geo.G ? (uint32_t)left : geo.G);
     g.n_start = g.w0 * ((uint64_t)geo.S * geo.D);                    // LowPass reads inner at off*D (src/filter.rs:71)
+    if constexpr (!GeoT::kFixed) {
+        if (P.row_offsets && g.valid) g.n_start = P.row_offsets[g.w0 - P.out_window0];   // irregular rows (take_fft), uniform load
+    }
     g.tile_raw = g.valid ? (g.g_cnt - 1) * geo.S * geo.D + geo.W * geo.D + geo.T : 0u;   // B*D + T (src/filter.rs:68)
     g.r0 = g.n_start / ROW;
     g.rel0 = (int32_t)(int64_t)(g.r0 * ROW - g.n_start);
@@ -175,20 +181,20 @@ __device__ __forceinline__ TileGeo tile_geo(const ChainParams &P, const GeoT &ge
 // stay in bounds, there is no branch, and the load writes its destination register directly —
 // nothing forces an early s_waitcnt.  The host never hands this path a vector that straddles the
 // slab end.  !ALIGNED (slab start not vector aligned): per-sample loads, correctness path.
-template <int FMT, bool ALIGNED>
+template <int FMT, int NT, bool ALIGNED>
 __device__ __forceinline__ typename FmtTraits<FMT>::Vec fetch_row(const ChainParams &P, const TileGeo &g, uint32_t i,
                                                                     uint32_t tid) {
     using FT = FmtTraits<FMT>;
     using Vec = typename FT::Vec;
     constexpr int SPL = FT::SPL, BPS = FT::BPS;
-    constexpr int32_t ROWB = kThreads * SPL * BPS, VECB = SPL * BPS;
+    constexpr int32_t ROWB = NT * SPL * BPS, VECB = SPL * BPS;
     if constexpr (ALIGNED) {
         const int64_t row_off = g.row0_off + (int64_t)i * ROWB;                                    // uniform
         // Legal lane offsets relative to this row (all 32-bit, wave-uniform): inside the slab AND
         // inside the tile, so lanes past the tile's edge collapse onto its first / last needed
         // vector (one cache line instead of a row of never-used bytes).
         constexpr int32_t LOGV = FMT == 0 ? 4 : (FMT == 3 ? 4 : 3);                                // log2(VECB)
-        const int32_t rel_i = g.rel0 + (int32_t)(i * (kThreads * SPL));                            // row start - tile start
+        const int32_t rel_i = g.rel0 + (int32_t)(i * (NT * SPL));                                  // row start - tile start
         const int32_t tlo = ((-rel_i * BPS) >> LOGV) << LOGV;                                      // vector holding the first tile byte
         const int32_t thi = (((-rel_i + (int32_t)g.tile_raw) * BPS - 1) >> LOGV) << LOGV;          // ... the last tile byte
         int32_t lo_rel = g.slab_lo0 - (int32_t)(i * ROWB), hi_rel = g.slab_hi0 - (int32_t)(i * ROWB);
@@ -202,7 +208,7 @@ __device__ __forceinline__ typename FmtTraits<FMT>::Vec fetch_row(const ChainPar
         const uint8_t *rowp = P.src + row_off;                                                     // uniform base
         return *reinterpret_cast<const Vec *>(rowp + t);
     } else {
-        const int32_t m0 = g.rel0 + (int32_t)(i * (kThreads * SPL)) + (int32_t)(tid * SPL);
+        const int32_t m0 = g.rel0 + (int32_t)(i * (NT * SPL)) + (int32_t)(tid * SPL);
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
@@ -240,13 +246,13 @@ __device__ __forceinline__ uint32_t pad_index(const GeoT &geo, uint32_t m) {
 // unpack -> NCO -> park in LDS for one fetched row.
 // NCO: 0 = no shift, 1 = first-order, 2 = second-order correction.  INTERIOR rows lie wholly
 // inside the tile, so no per-sample bounds checks are needed (a wave-uniform property).
-template <int FMT, int NCO, bool INTERIOR, class GeoT>
+template <int FMT, int NT, int NCO, bool INTERIOR, class GeoT>
 __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &geo, const TileGeo &g, int32_t rel,
                                             uint32_t tid, const typename FmtTraits<FMT>::Vec &v, const RowBase &rb,
                                             const LaneRot *lr, uint32_t lane_pad, const float *lut, float2 *raw) {
     using FT = FmtTraits<FMT>;
     constexpr int SPL = FT::SPL;
-    constexpr uint32_t ROW = kThreads * SPL;
+    constexpr uint32_t ROW = NT * SPL;
     const int32_t m0 = rel + (int32_t)(tid * SPL);
     if constexpr (!INTERIOR) {
         if (!(m0 + SPL > 0 && m0 < (int32_t)g.tile_raw)) return;
@@ -292,16 +298,16 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
     }
 }
 
-template <int FMT, int NCO, class GeoT>
+template <int FMT, int NT, int NCO, class GeoT>
 __device__ __forceinline__ void process_row_any(const ChainParams &P, const GeoT &geo, const TileGeo &g, uint32_t i,
                                                 uint32_t tid, const typename FmtTraits<FMT>::Vec &v, const RowBase &rb,
                                                 const LaneRot *lr, uint32_t lane_pad, const float *lut, float2 *raw) {
-    constexpr uint32_t ROW = kThreads * FmtTraits<FMT>::SPL;
+    constexpr uint32_t ROW = NT * FmtTraits<FMT>::SPL;
     const int32_t rel = g.rel0 + (int32_t)(i * ROW);                                              // wave-uniform
     if (rel >= 0 && rel + (int32_t)ROW <= (int32_t)g.tile_raw)
-        process_row<FMT, NCO, true>(P, geo, g, rel, tid, v, rb, lr, lane_pad, lut, raw);
+        process_row<FMT, NT, NCO, true>(P, geo, g, rel, tid, v, rb, lr, lane_pad, lut, raw);
     else
-        process_row<FMT, NCO, false>(P, geo, g, rel, tid, v, rb, lr, lane_pad, lut, raw);
+        process_row<FMT, NT, NCO, false>(P, geo, g, rel, tid, v, rb, lr, lane_pad, lut, raw);
 }
 
 // ---------------------------------------------------------------- FIR
@@ -343,7 +349,7 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
             // long filters, software-pipelined by hand: the LDS reads of block k+1 (8 taps: samples +
             // tap values) are issued before block k is consumed, so the dependent multiply/accumulate
             // chain does not stall on LDS latency after every pair.
-            constexpr uint32_t B = 8;
+            constexpr uint32_t B = GeoT::kFirBlock;
             float2 xa[B]; float ha[B];
 #pragma unroll
             for (uint32_t i = 0; i < B; ++i) if (i < n) { xa[i] = rowp[lds_index(i)]; ha[i] = h[i]; }
@@ -398,8 +404,8 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
 //   during the FIR/FFT phases (prefetch distance = one tile).
 //   Chunked (bigger tiles): RCH rows ahead within the tile, the next tile's first chunk at its end.
 // LB: waves per SIMD the build is register-budgeted for (__launch_bounds__ 2nd argument).
-template <int FMT, int NCO, class GeoT, bool HAS_FIR, int RCH, bool WHOLE, bool ALIGNED, int LB>
-__global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
+template <int FMT, int NCO, class GeoT, bool HAS_FIR, int RCH, bool WHOLE, bool ALIGNED, int LB, int NT = kThreads>
+__global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     using FT = FmtTraits<FMT>;
     using Vec = typename FT::Vec;
     constexpr int SPL = FT::SPL;
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
 
-    if constexpr (FMT == 1) lut[tid] = unpack_cs8(tid);
-    if constexpr (FMT == 2) lut[tid] = unpack_cu8(tid);
+    if constexpr (FMT == 1) { if (tid < 256) lut[tid] = unpack_cs8(tid); }
+    if constexpr (FMT == 2) { if (tid < 256) lut[tid] = unpack_cu8(tid); }
 
     LaneRot lr[SPL];
     if constexpr (HAS_SHIFT) {
@@ -436,11 +442,11 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
     // them has to wait behind the next tile's prefetch (vmcnt retires in order).
     {
         const uint32_t n_tw = W - geo.base_len;               // 3*(base + 4*base + ...) = W - base
-        for (uint32_t i = tid; i < n_tw; i += kThreads) twl[i] = P.tw[i];
+        for (uint32_t i = tid; i < n_tw; i += NT) twl[i] = P.tw[i];
         // ... and the taps: the FIR loop then contains LDS reads only, so its waits are counted
         // lgkmcnt(N) instead of a full drain per batch (scalar loads share that counter and return
         // out of order, which forces lgkmcnt(0)).
-        for (uint32_t i = tid; i < T; i += kThreads) tapl[i] = P.taps[i];
+        for (uint32_t i = tid; i < T; i += NT) tapl[i] = P.taps[i];
     }
     __syncthreads();
 
@@ -449,11 +455,11 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
     // Register prefetch pipeline.  Slots whose row does not exist in the tile re-load its last
     // row (an L2 hit) so that every load stays unconditional.
     uint64_t tile = blockIdx.x;
-    TileGeo tg = tile_geo<FMT>(P, geo, tile, n_tiles);
+    TileGeo tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
     Vec pf[RCH];
     if (tg.valid) {
 #pragma unroll
-        for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, ALIGNED>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
+        for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, NT, ALIGNED>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
     }
 
     QD_STAMP_DECL
@@ -464,20 +470,20 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
 
         // ---------------- phase 1: HBM -> unpack -> NCO -> LDS
         if constexpr (WHOLE) {
-            TileGeo ng = tile_geo<FMT>(P, geo, tile + gridDim.x, n_tiles);
+            TileGeo ng = tile_geo<FMT, NT>(P, geo, tile + gridDim.x, n_tiles);
             if (!ng.valid) ng = tg;                  // last tile of this workgroup: harmless re-loads
             RowBase rb_next{};
             if constexpr (HAS_SHIFT) rb_next = load_rowbase(P, tg.r0);
 #pragma unroll
             for (int i = 0; i < RCH; ++i) {
                 const Vec v = pf[i];
-                pf[i] = fetch_row<FMT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
+                pf[i] = fetch_row<FMT, NT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
                 if ((uint32_t)i < tg.n_rows) {
                     const RowBase rb = rb_next;
                     if constexpr (HAS_SHIFT) {           // scalar load for the next row while this one computes
                         if ((uint32_t)i + 1 < tg.n_rows) rb_next = load_rowbase(P, tg.r0 + i + 1);
                     }
-                    process_row_any<FMT, NCO>(P, geo, tg, i, tid, v, rb, lr, lane_pad, lut, raw);
+                    process_row_any<FMT, NT, NCO>(P, geo, tg, i, tid, v, rb, lr, lane_pad, lut, raw);
                 }
             }
         } else {
@@ -488,12 +494,12 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                 TileGeo ng = tg;
                 uint32_t rbase = r + RCH;
                 if (rbase >= tg.n_rows) {
-                    const TileGeo t2 = tile_geo<FMT>(P, geo, tile + gridDim.x, n_tiles);
+                    const TileGeo t2 = tile_geo<FMT, NT>(P, geo, tile + gridDim.x, n_tiles);
                     if (t2.valid) { ng = t2; rbase = 0; } else { rbase = tg.n_rows - 1; }
                 }
 #pragma unroll
                 for (int i = 0; i < RCH; ++i)
-                    pf[i] = fetch_row<FMT, ALIGNED>(P, ng, rbase + i < ng.n_rows ? rbase + i : ng.n_rows - 1, tid);
+                    pf[i] = fetch_row<FMT, NT, ALIGNED>(P, ng, rbase + i < ng.n_rows ? rbase + i : ng.n_rows - 1, tid);
                 RowBase rb[RCH];
 #pragma unroll
                 for (int i = 0; i < RCH; ++i) {
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
                 }
 #pragma unroll
                 for (int i = 0; i < RCH; ++i)
-                    if (r + i < tg.n_rows) process_row_any<FMT, NCO>(P, geo, tg, r + i, tid, cur[i], rb[i], lr, lane_pad, lut, raw);
+                    if (r + i < tg.n_rows) process_row_any<FMT, NT, NCO>(P, geo, tg, r + i, tid, cur[i], rb[i], lr, lane_pad, lut, raw);
             }
         }
         QD_STAMP_AT(0);
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
         const uint32_t n_out = g_cnt << logW;
         const uint32_t log_width = 2 * geo.layers;   // width = W / base_len = 4^layers
-        for (uint32_t o = tid; o < n_out; o += kThreads) {
+        for (uint32_t o = tid; o < n_out; o += NT) {
             const uint32_t g = o >> logW, k = o & (W - 1);
             const uint32_t q = g * S + k;
             float accr = 0.f, acci = 0.f;
@@ -533,6 +539,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
             } else {
                 float2 v = raw[HAS_FIR ? q * Dp : q];
                 accr = v.x; acci = v.y;
+                if constexpr (!GeoT::kFixed && !HAS_FIR) {
+                    if (P.window) { const float wv = P.window[k]; accr = accr * wv; acci = acci * wv; }   // Complex<f32> * f32
+                }
             }
             // bitreversed_transpose::<4>(base_len, ..): out[y + rev(x)*base] = in[x + y*width]
             const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
             const uint32_t base = geo.base_len;
             const uint32_t log_tpw = logW - geo.log_base;   // base tasks per window = W / base
             const uint32_t n_task = g_cnt << log_tpw;
-            for (uint32_t t = tid; t < n_task; t += kThreads) {
+            for (uint32_t t = tid; t < n_task; t += NT) {
                 // windows are contiguous in fb, so task t owns chunk t
                 float2 *d = fb + (size_t)t * base;
                 if (base == 16) {
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
             for (uint32_t layer = 0; layer < geo.layers; ++layer) {
                 __syncthreads();
                 const uint32_t n_bf = (g_cnt << logW) >> 2;   // W/4 butterflies per window
-                for (uint32_t t = tid; t < n_bf; t += kThreads) {
+                for (uint32_t t = tid; t < n_bf; t += NT) {
                     // butterfly t: chunk (of 4*cols; windows are contiguous) t >> log_cols, column t & (cols-1)
                     const uint32_t chunk = t >> log_cols, i = t & (cols - 1);
                     float2 *d = fb + (size_t)chunk * 4 * cols + i;
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
         if (P.epi == 2) {
             // freq_levels (src/fft.rs:95-97): sequential f32 sums of |X[k]| over each half
             float *nb = reinterpret_cast<float *>(raw);       // raw tile is dead now
-            for (uint32_t o = tid; o < n_out; o += kThreads) nb[o] = norm_ref(fb[o]);
+            for (uint32_t o = tid; o < n_out; o += NT) nb[o] = norm_ref(fb[o]);
             __syncthreads();
             if (tid < g_cnt) {
                 const float *p = nb + (tid << logW);
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
         } else {
             float *outf = reinterpret_cast<float *>(P.out) + (wrel << logW);     // uniform base
             uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << logW);
-            for (uint32_t o = tid; o < n_out; o += kThreads) {
+            for (uint32_t o = tid; o < n_out; o += NT) {
                 const float2 xv = fb[o ^ (W >> 1)];           // fftshift: bin (b + W/2) mod W of the same window
                 const float nm = (P.dbg & 8) ? xv.x : norm_ref(xv);
                 if (P.epi == 0) outf[o] = nm;
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_chain(const ChainParams P) {
         QD_STAMP_AT(7);
         QD_STAMP_TILE();
         tile += gridDim.x;
-        tg = tile_geo<FMT>(P, geo, tile, n_tiles);
+        tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
     }
     QD_STAMP_FLUSH();
 }

@@ -230,12 +230,15 @@ chain_fn pick_generic(int fmt, int nco, bool fir, bool aligned) {
 struct FixedEntry {
     int fmt, nco;
     uint32_t W, S, D, T, G;
-    int wg_per_cu;       // register budget the build targets (waves per SIMD == 256-thread blocks per CU)
+    int wg_per_cu;       // register budget the build targets (waves per SIMD)
+    int nt;              // workgroup size
     chain_fn fn;
     const char *name;
 };
 #define QD_FIXED(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NAME) \
-    { F, NCO, W, S, D, T, G, LB, k_chain<F, NCO, FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
+    { F, NCO, W, S, D, T, G, LB, kThreads, k_chain<F, NCO, FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
+#define QD_FIXED_NT(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, NAME) \
+    { F, NCO, W, S, D, T, G, LB, NT, k_chain<F, NCO, FixedGeo<W, S, D, T, G, FIRB>, true, RCH, WHOLE, true, LB, NT>, NAME }
 const FixedEntry kFixed[] = {
     // configs[1]  "shift 280000 | lowpass -power 20 -decimate 16 2000000 | sparkfft -width 128"   (README.md:57-63)
     QD_FIXED(0, 1, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
@@ -251,7 +254,8 @@ const FixedEntry kFixed[] = {
     QD_FIXED(1, 2, 64, 16, 32, 400, 4, 5, true, 4, "cfg3"),
 #endif
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
-    QD_FIXED(0, 0, 1024, 1024, 8, 512, 1, 4, false, 4, "cfg4"),
+    // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
+    QD_FIXED_NT(0, 0, 1024, 1024, 8, 512, 1, 5, true, 4, 1024, 4, "cfg4"),
 };
 
 const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t D, uint32_t T) {
@@ -297,11 +301,14 @@ struct qd_plan {
     Geometry geo;
     chain_fn fn = nullptr, fn_unaligned = nullptr;
     const FixedEntry *fixed = nullptr;
-    int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0;
+    int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0, nt = kThreads;
     // NCO tables
     double2 *jtab_d = nullptr;
     RowBase *rowtab_d = nullptr;
     uint64_t rowtab_row0 = 0, rowtab_rows = 0;
+    // take_fft mode (generic kernels): per-window start offsets and an f32 window, both on the device
+    const uint64_t *row_offsets_d = nullptr;
+    const float *window_d = nullptr;
     // timing
     bool timing = false, ev_made = false, ev_recorded = false;
     hipEvent_t ev0{}, ev1{};
@@ -325,7 +332,7 @@ uint64_t out_bytes_per_window(const qd_plan *p) {
 
 int ensure_rowtab(qd_plan *p, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
     if (!p->has_shift) return QD_OK;
-    const uint32_t ROW = kThreads * spl_of(p->d.format);
+    const uint32_t ROW = p->nt * spl_of(p->d.format);
     uint64_t r_lo = n_lo / ROW, r_hi = (n_hi + ROW - 1) / ROW + 1;
     if (p->rowtab_d && r_lo >= p->rowtab_row0 && r_hi <= p->rowtab_row0 + p->rowtab_rows) return QD_OK;
     if (p->rowtab_d) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(p->rowtab_d)); p->rowtab_d = nullptr; }
@@ -345,7 +352,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     const int spl = spl_of(fmt), bps = bps_of(fmt);
     uint64_t need0 = first_window * p->S * p->D;
     uint64_t need1 = (first_window + n_windows - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
-    if (need0 < src_first || need1 > src_first + src_count)
+    if (!p->row_offsets_d && (need0 < src_first || need1 > src_first + src_count))
         return fail(QD_ERR_INVALID, "src slab [%llu,+%llu) does not cover samples [%llu,%llu) needed by windows [%llu,+%llu)",
                     (unsigned long long)src_first, (unsigned long long)src_count, (unsigned long long)need0,
                     (unsigned long long)need1, (unsigned long long)first_window, (unsigned long long)n_windows);
@@ -376,6 +383,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     P.rowtab = p->rowtab_d; P.rowtab_row0 = p->rowtab_row0;
     P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
     P.out = out_d;
+    P.row_offsets = p->row_offsets_d; P.window = p->window_d;
     if (const char *e = getenv("QD_DEBUG_SKIP")) P.dbg = (uint32_t)atoi(e);   // timing-only ablation, never set in tests/bench
 #ifdef QD_STAMP
     static unsigned long long *stamps_d = nullptr;
@@ -397,6 +405,8 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         n_aligned = n_windows;
         while (n_aligned > 0 && (first_window + n_aligned - 1) * step + rpw > usable) --n_aligned;
     }
+    if (n_aligned < n_windows && p->nt != kThreads && p->has_shift)
+        return fail(QD_ERR_UNSUPPORTED, "unaligned slab with a %d-thread shifted plan: NCO tables are laid out for that row length", p->nt);
     uint64_t cap = (uint64_t)p->n_cu * p->wg_per_cu;
     if (const char *e = getenv("QD_WG_PER_CU")) cap = (uint64_t)p->n_cu * (uint64_t)atoi(e);   // tuning knob
     if (p->timing) {
@@ -410,7 +420,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         P.first_window = w_begin; P.n_windows = w_count;
         const uint64_t n_tiles = (w_count + P.G - 1) / P.G;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
-        hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(kThreads), p->geo.lds_bytes, st, P);
+        hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->nt : kThreads), p->geo.lds_bytes, st, P);
         HIPCHK(hipGetLastError());
     }
     if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
@@ -513,6 +523,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->fixed = p->has_fir ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
     if (p->fixed) {
         G = p->fixed->G;
+        p->nt = p->fixed->nt;
     } else {
         while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 40 * 1024) G *= 2;
         while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 36 * 1024) G *= 2;
@@ -532,6 +543,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     int by_lds = (int)(kLdsMax / p->geo.lds_bytes);
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed && p->wg_per_cu > p->fixed->wg_per_cu) p->wg_per_cu = p->fixed->wg_per_cu;
+    if (p->nt > kThreads) { int by_threads = 2048 / p->nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
     for (chain_fn f : {p->fn, p->fn_unaligned}) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)p->geo.lds_bytes);
@@ -552,7 +564,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         HIPCHK(hipMemcpy(p->taps_d, p->taps_h.data(), p->T * sizeof(float), hipMemcpyHostToDevice));
     }
     if (p->has_shift) {
-        const uint32_t ROW = kThreads * spl_of(d.format);
+        const uint32_t ROW = p->nt * spl_of(d.format);
         HIPCHK(hipMalloc(&p->jtab_d, ROW * sizeof(double2)));
         hipLaunchKernelGGL(k_jtab, dim3((ROW + 255) / 256), dim3(256), 0, 0, p->ratio, ROW, p->jtab_d);
         HIPCHK(hipGetLastError());
@@ -622,7 +634,7 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->raw_step = (uint64_t)p->S * p->D;
     info->ratio = p->ratio;
     info->tile_windows = p->geo.G;
-    info->threads = kThreads;
+    info->threads = (uint32_t)p->nt;
     info->lds_bytes = (uint32_t)p->geo.lds_bytes;
     return QD_OK;
 }
@@ -824,6 +836,77 @@ int qd_fft_norm_batch(const qd_c32 *in, size_t W, size_t n_fft, size_t in_stride
     if (rc == QD_OK && mem == QD_MEM_DEVICE) { if (hipDeviceSynchronize() != hipSuccess) rc = fail(QD_ERR_HIP, "sync failed"); }
     qd_plan_destroy(p);
     return rc;
+}
+
+int qd_take_fft(const qd_c32 *in, uint64_t in_first, size_t n_in, uint64_t samples_len, int has_slice,
+                uint64_t start, uint64_t end, size_t W, int windowing, size_t output_len, float *rows, int mem) {
+    if (!in || !rows) return fail(QD_ERR_INVALID, "NULL buffer");
+    if (!is_pow2(W)) return fail(QD_ERR_UNSUPPORTED, "take_fft width %zu: only power-of-two widths are built (the reference's planner takes any)", W);
+    if (!has_slice) {                                                             // src/ffts.rs:27-30
+        if (samples_len < W) return fail(QD_ERR_PANIC, "len < width underflows (src/ffts.rs:29)");
+        start = 0; end = samples_len - W;
+    }
+    if (!(end > start)) return fail(QD_ERR_PANIC, "Invalid slice: end (%llu) must be greater than start (%llu)", (unsigned long long)end, (unsigned long long)start);
+    if (!(end < samples_len)) return fail(QD_ERR_PANIC, "Slice end (%llu) exceeds sample length (%llu)", (unsigned long long)end, (unsigned long long)samples_len);
+    const uint64_t visible = end - start;
+    if (!(visible > output_len)) return fail(QD_ERR_INVALID, "Visible samples (%llu) must be greater than output length (%zu)", (unsigned long long)visible, output_len);
+    if (output_len == 0) return QD_OK;
+    // row offsets exactly as the reference forms them (f64 step, round half away from zero, saturating cast)
+    const double step = (double)visible / (double)output_len;                     // :50
+    std::vector<uint64_t> offs(output_len);
+    for (size_t i = 0; i < output_len; ++i) {
+        double r = std::round(step * (double)i);
+        uint64_t ri = !(r > 0) ? 0 : (r >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)r);
+        offs[i] = start + ri;                                                     // :60
+        if (offs[i] < in_first || offs[i] + W > in_first + n_in || offs[i] + W > samples_len)
+            return fail(QD_ERR_SHORT, "row %zu at sample %llu is not inside the provided block / the stream (read_exact_at, src/ffts.rs:62)", i, (unsigned long long)offs[i]);
+    }
+    std::vector<float> win;
+    if (windowing == 1) {                                                         // generate_blackman_harris_window, :110-119
+        win.resize(W);
+        const float tau = 6.28318530717958647692528676655900577f;
+        for (size_t i = 0; i < W; ++i) {
+            float x = tau * (float)i / (float)(W - 1);
+            win[i] = 0.35875f - 0.48829f * std::cos(x) + 0.14128f * std::cos(2.0f * x) - 0.01168f * std::cos(3.0f * x);
+        }
+    }
+    qd_chain_desc d{};
+    d.struct_size = sizeof d;
+    d.format = QD_FMT_CF32; d.sample_rate = 1;
+    d.n_samples = (uint64_t)output_len * W + 1;        // only sizes the sink loop: output_len windows at stride W
+    d.width = W; d.stride = W; d.epilogue = QD_EPI_NORMS_F32;
+    qd_plan *p = nullptr;
+    int rc = qd_plan_create(&d, &p);
+    if (rc) return rc;
+    DevBuf doffs, dwin, din, dout;
+    auto cleanup = [&](int r) { qd_plan_destroy(p); return r; };
+    p->geo.G = 1;                                       // one irregular row per tile
+    {
+        uint32_t raw_elems = 0;
+        p->geo.lds_bytes = lds_for(1, p->W, p->S, p->D, p->T, &raw_elems);
+        p->geo.lds_raw_elems = raw_elems;
+    }
+    if (hipMalloc(&doffs.p, output_len * 8) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "hipMalloc offsets"));
+    if (hipMemcpy(doffs.p, offs.data(), output_len * 8, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "copy offsets"));
+    p->row_offsets_d = static_cast<const uint64_t *>(doffs.p);
+    if (!win.empty()) {
+        if (hipMalloc(&dwin.p, W * 4) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "hipMalloc window"));
+        if (hipMemcpy(dwin.p, win.data(), W * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "copy window"));
+        p->window_d = static_cast<const float *>(dwin.p);
+    }
+    const void *src = in; void *dst = rows;
+    if (mem == QD_MEM_HOST) {
+        if (hipMalloc(&din.p, n_in * 8) != hipSuccess || hipMalloc(&dout.p, output_len * W * 4) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "hipMalloc"));
+        if (hipMemcpy(din.p, in, n_in * 8, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "H2D"));
+        src = din.p; dst = dout.p;
+    }
+    // rows are irregular: the per-sample kernel (no vector-alignment assumptions) reads them
+    p->fn = p->fn_unaligned;
+    p->d.n_samples = in_first + n_in;
+    rc = launch_chain(p, src, in_first, n_in, 0, output_len, 0, dst, nullptr);
+    if (rc == QD_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(QD_ERR_HIP, "sync failed");
+    if (rc == QD_OK && mem == QD_MEM_HOST && hipMemcpy(rows, dout.p, output_len * W * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(QD_ERR_HIP, "D2H");
+    return cleanup(rc);
 }
 
 int qd_gen(const int64_t *cos_hz, size_t n_cos, uint64_t sample_rate, uint64_t first, size_t n, qd_c32 *out, int mem) {

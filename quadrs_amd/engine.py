@@ -85,6 +85,17 @@ def gen(cos_hz, sample_rate, first, n):
     return out
 
 
+def take_fft(x, width, output_len, slice_=None, windowing=1, in_first=0, samples_len=None):
+    """take_fft (src/ffts.rs:18-85) over cf32 samples x = samples [in_first, in_first+len(x)) of the viewed stream."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 2)
+    samples_len = in_first + x.shape[0] if samples_len is None else samples_len
+    rows = np.zeros((output_len, width), dtype=np.float32)
+    s, e = slice_ if slice_ else (0, 0)
+    check(lib().qd_take_fft(_np_ptr(x), in_first, x.shape[0], samples_len, 1 if slice_ else 0, s, e, width, windowing,
+                            output_len, _np_ptr(rows), MEM_HOST))
+    return rows
+
+
 class Plan:
     """The fused chain  from -> [shift] -> [lowpass] -> sparkfft|bucket  (Operation::exec, src/lib.rs:83-175)."""
 

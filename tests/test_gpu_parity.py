@@ -207,7 +207,8 @@ CHAINS = [
     (0, 300_000, 280000, (2_000_000, 16, 40), 128, 128),      # cfg 2 shape
     (1, 200_000, 280000, (200_000, 32, 400), 64, 16),         # cfg 3 shape (cs8, overlapping windows)
     (0, 400_000, 280000, (200_000, 32, 200), 128, 128),       # cfg 3' shape
-    (0, 150_000, 1_000_000, (5_000_000, 8, 512), 1024, 1024), # cfg 4 shape
+    (0, 150_000, 1_000_000, (5_000_000, 8, 512), 1024, 1024), # cfg 4 shape with a shift (generic kernel)
+    (0, 150_000, None, (5_000_000, 8, 512), 1024, 1024),      # cfg 4 exactly (1024-thread specialised kernel)
     (2, 100_000, -500_000, (1_000_000, 8, 40), 32, 8),        # cu8, negative shift
     (3, 100_000, 123_456, (700_000, 10, 24), 16, 5),          # cs16, D not a power of two
     (0, 60_000, None, (2_000_000, 16, 40), 128, 64),          # no shift
@@ -321,6 +322,33 @@ def test_device_resident_run_equals_host_run(engine):
     p.run_device(src, out2)
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("W,out_len,windowing,slice_", [(256, 32, 1, None), (64, 100, 0, (1000, 40_000)), (1024, 7, 1, (5, 60_000)),
+                                                         (4, 2048, 1, None)])
+def test_take_fft_rows(engine, oracle, fsk, W, out_len, windowing, slice_):
+    """A8: take_fft (src/ffts.rs:18-85) — row offsets, Blackman-Harris window, FFT, fftshifted norms."""
+    x = np.frombuffer(fsk, dtype=np.float32).reshape(-1, 2)
+    rc, ref, offs = oracle.Chain.from_bytes(fsk, oracle.FMT_CF32, 21_000_000).take_fft(W, out_len, slice_, windowing)
+    assert rc == 0
+    got = engine.take_fft(x, W, out_len, slice_, windowing)
+    assert bits_equal(ref, got)
+    # a caller may hand over only the block the rows touch
+    lo, hi = int(offs.min()), int(offs.max()) + W
+    got2 = engine.take_fft(x[lo:hi], W, out_len, slice_ if slice_ else (0, x.shape[0] - W), windowing, in_first=lo,
+                           samples_len=x.shape[0])
+    assert bits_equal(ref, got2)
+
+
+def test_take_fft_errors(engine, fsk):
+    x = np.frombuffer(fsk, dtype=np.float32).reshape(-1, 2)[:5000]
+    for kw, code in ((dict(width=100, output_len=8), 5),                    # planner widths: not built
+                     (dict(width=64, output_len=8, slice_=(10, 10)), 2),    # end > start assert
+                     (dict(width=64, output_len=8, slice_=(10, 5000)), 2),  # end < len assert
+                     (dict(width=64, output_len=6000), 1)):                 # ensure!(visible > output_len)
+        with pytest.raises(engine.QuadrsError) as ei:
+            engine.take_fft(x, **kw)
+        assert ei.value.code == code, kw
 
 
 def test_gen_against_golden(engine, vec):
