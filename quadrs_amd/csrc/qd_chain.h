@@ -227,6 +227,19 @@ __device__ __forceinline__ typename FmtTraits<FMT>::Vec fetch_row(const ChainPar
     }
 }
 
+// The row table is streamed (32 B per row) and read with scalar loads one row ahead; without help
+// every other row base is a cold HBM miss through the scalar cache (~1000+ cycles).  So a few lanes
+// touch the NEXT tile's entries with a vector load a whole tile early: the lines are then in this
+// XCD's L2 when the scalar loads come.  The value is only summed into a never-stored register.
+template <bool HAS_SHIFT>
+__device__ __forceinline__ double prefetch_rowtab(const ChainParams &P, const TileGeo &ng, uint32_t tid) {
+    double v = 0.0;
+    if constexpr (HAS_SHIFT) {
+        if (tid < ng.n_rows) v = *reinterpret_cast<const volatile double *>(&P.rowtab[ng.r0 - P.rowtab_row0 + tid].c);
+    }
+    return v;
+}
+
 // scalar (wave-uniform) load of one row base
 __device__ __forceinline__ RowBase load_rowbase(const ChainParams &P, uint64_t r) {
     const_f64_p rp = (const_f64_p)(uintptr_t)(P.rowtab + (r - P.rowtab_row0));
@@ -462,6 +475,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, NT, ALIGNED>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
     }
 
+    double rt_touch = 0.0;   // keeps the row-table L2 prefetch loads alive (see prefetch_rowtab)
     QD_STAMP_DECL
     QD_STAMP_START();
     while (tg.valid) {
@@ -469,9 +483,11 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         const uint32_t g_cnt = tg.g_cnt;
 
         // ---------------- phase 1: HBM -> unpack -> NCO -> LDS
+        double rt_pf = 0.0;
         if constexpr (WHOLE) {
             TileGeo ng = tile_geo<FMT, NT>(P, geo, tile + gridDim.x, n_tiles);
             if (!ng.valid) ng = tg;                  // last tile of this workgroup: harmless re-loads
+            rt_pf = prefetch_rowtab<HAS_SHIFT>(P, ng, tid);
             RowBase rb_next{};
             if constexpr (HAS_SHIFT) rb_next = load_rowbase(P, tg.r0);
 #pragma unroll
@@ -495,7 +511,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 uint32_t rbase = r + RCH;
                 if (rbase >= tg.n_rows) {
                     const TileGeo t2 = tile_geo<FMT, NT>(P, geo, tile + gridDim.x, n_tiles);
-                    if (t2.valid) { ng = t2; rbase = 0; } else { rbase = tg.n_rows - 1; }
+                    if (t2.valid) { ng = t2; rbase = 0; rt_pf = prefetch_rowtab<HAS_SHIFT>(P, t2, tid); } else { rbase = tg.n_rows - 1; }
                 }
 #pragma unroll
                 for (int i = 0; i < RCH; ++i)
@@ -633,6 +649,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 else outb[o] = glyph_code(nm, P.rmin, P.rmax);
             }
         }
+        rt_touch += rt_pf;       // first use of the touch loads: a whole tile after they were issued
         QD_STAMP_AT(6);
         __syncthreads();
         QD_STAMP_AT(7);
@@ -641,6 +658,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
     }
     QD_STAMP_FLUSH();
+    if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
 }
 
 }  // namespace qd
