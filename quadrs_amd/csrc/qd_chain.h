@@ -28,10 +28,11 @@ namespace qd {
 
 // In-kernel phase stamps (cdna_hip_programming.md §7): diagnostic build only, never in the shipped .so.
 #ifdef QD_STAMP
-#define QD_STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned st_tiles = 0;
+#define QD_STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_row[4] = {0, 0, 0, 0}; unsigned st_tiles = 0;
+#define QD_STAMP_ROW(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_row[k] += t_ - st_prev; st_acc[0] += t_ - st_prev; st_prev = t_; } while (0)
 #define QD_STAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); } while (0)
 #define QD_STAMP_AT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 0) atomicAdd(&P.stamps[32], (unsigned long long)st_tiles); } } while (0)
+#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 1) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[33 + k_], st_row[k_]); if (w_ == 0) atomicAdd(&P.stamps[32], (unsigned long long)st_tiles); } } while (0)
 #define QD_STAMP_TILE() do { ++st_tiles; } while (0)
 #else
 #define QD_STAMP_DECL
@@ -39,6 +40,7 @@ namespace qd {
 #define QD_STAMP_AT(k)
 #define QD_STAMP_FLUSH()
 #define QD_STAMP_TILE()
+#define QD_STAMP_ROW(k)
 #endif
 
 constexpr int kThreads = 256;
@@ -493,13 +495,23 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 #pragma unroll
             for (int i = 0; i < RCH; ++i) {
                 const Vec v = pf[i];
+#ifdef QD_STAMP
+                asm volatile("" :: "v"(v.x), "v"(v.y));      // force the wait for this row's data here
+                QD_STAMP_ROW(0);
+#endif
                 pf[i] = fetch_row<FMT, NT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
+                QD_STAMP_ROW(1);
                 if ((uint32_t)i < tg.n_rows) {
                     const RowBase rb = rb_next;
+#ifdef QD_STAMP
+                    asm volatile("" :: "s"(rb.c), "s"(rb.nf));
+                    QD_STAMP_ROW(2);
+#endif
                     if constexpr (HAS_SHIFT) {           // scalar load for the next row while this one computes
                         if ((uint32_t)i + 1 < tg.n_rows) rb_next = load_rowbase(P, tg.r0 + i + 1);
                     }
                     process_row_any<FMT, NT, NCO>(P, geo, tg, i, tid, v, rb, lr, lane_pad, lut, raw);
+                    QD_STAMP_ROW(3);
                 }
             }
         } else {

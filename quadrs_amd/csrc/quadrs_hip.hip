@@ -439,7 +439,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
             for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s=%.0f", names[k], h[w * 8 + k] / tiles); tot += h[w * 8 + k] / tiles; }
             fprintf(stderr, "  total=%.0f", tot);
         }
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n   wave1 phase-1 split per tile: wait_data=%.0f issue_prefetch=%.0f wait_rowbase=%.0f process=%.0f\n", h[33] / tiles, h[34] / tiles, h[35] / tiles, h[36] / tiles);
     }
 #endif
     return QD_OK;
