@@ -126,10 +126,13 @@ struct FixedGeo {
     static constexpr uint32_t base_len = 1u << log_base;
     static constexpr uint32_t layers = (logW - log_base) / 2;
     static constexpr uint32_t lds_raw_elems = ct_raw_elems(W_, S_, D_, T_, G_);
+    static constexpr uint32_t kNtrunc = c ? (c + D_ - 1) / D_ - 1 : 0;
+    static constexpr bool kShared = T_ > 0 && S_ < W_ && kNtrunc <= S_;     // shared-FIR mode (see phase 2)
 };
 
 struct DynGeo {
     static constexpr bool kFixed = false;
+    static constexpr bool kShared = false;
     uint32_t W, S, D, T, G, logW, Dp, dshift, dmagic, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
     __device__ __forceinline__ explicit DynGeo(const ChainParams &P)
         : W(P.W), S(P.S), D(P.D), T(P.T), G(P.G), logW(P.logW), Dp(P.Dp), dshift(P.dshift), dmagic(P.dmagic),
@@ -336,7 +339,8 @@ __device__ __forceinline__ void process_row_any(const ChainParams &P, const GeoT
 // taps instead of a predicate on every tap past T_fast.
 template <bool PRED, class GeoT, bool SNAP = false>
 __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, uint32_t b, uint32_t j0, uint32_t j1,
-                                         uint32_t jmax, const float *__restrict__ taps, float &accr, float &acci) {
+                                         uint32_t jmax, const float *__restrict__ taps, float &accr, float &acci,
+                                         float2 *snap_out = nullptr) {
     const uint32_t D = geo.D, Dp = geo.Dp;
     const uint32_t n = j1 - j0;                       // taps to do
     const uint32_t n_rows = (b + n + D - 1) / D;      // LDS rows touched
@@ -359,6 +363,35 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                     accr = accr + x.x * hh;           // Complex<f32> * f32, then +=  (src/filter.rs:119)
                     acci = acci + x.y * hh;
                 }
+            }
+        } else if (n > 256 && GeoT::kFirBlock >= 8) {      // (kFirBlock 4 = a build that prefers the small-block pipelined form)
+            // very long filters: a ROLLED loop over LDS rows (D taps each) with an 8-tap inner unroll —
+            // fully unrolling 400-500 taps blows the register allocator up.  A lane's jmax can only be
+            // reached at ONE column of a row (column T % D, see is_snap), so the snapshot check is
+            // peeled to that column: one compare + two selects per row instead of per tap.
+            const uint32_t bstar = geo.T % D;                  // column where (tap - T/2) % D == 0
+            const float2 *rp = rowp;
+            uint32_t j = 0, bcur = b;
+            while (j < n) {                                    // wave-uniform trip structure
+                uint32_t run = D - bcur;
+                if (run > n - j) run = n - j;
+                // split [bcur, bcur+run) at bstar
+                uint32_t first = run;
+                if (SNAP && bstar >= bcur && bstar < bcur + run) first = bstar - bcur;
+#pragma unroll 8
+                for (uint32_t i = 0; i < first; ++i) {
+                    float2 x = rp[bcur + i]; float hh = h[j + i];
+                    if (!PRED || (j0 + j + i) < jmax) { accr = accr + x.x * hh; acci = acci + x.y * hh; }
+                }
+                if (SNAP && first < run) {
+                    if (is_snap(j0 + j + first)) { if (jmax == j0 + j + first) { snapr = accr; snapi = acci; } }
+#pragma unroll 8
+                    for (uint32_t i = first; i < run; ++i) {
+                        float2 x = rp[bcur + i]; float hh = h[j + i];
+                        if (!PRED || (j0 + j + i) < jmax) { accr = accr + x.x * hh; acci = acci + x.y * hh; }
+                    }
+                }
+                j += run; bcur = 0; rp += Dp;
             }
         } else {
             // long filters, software-pipelined by hand: the LDS reads of block k+1 (8 taps: samples +
@@ -389,7 +422,10 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                 for (uint32_t i = 0; i < B; ++i) { xa[i] = xb[i]; ha[i] = hb[i]; }
             }
         }
-        if (SNAP && jmax < geo.T) { accr = snapr; acci = snapi; }
+        if (SNAP) {
+            if (snap_out) *snap_out = make_float2(snapr, snapi);        // caller wants both the full and the truncated value
+            else if (jmax < geo.T) { accr = snapr; acci = snapi; }
+        }
     } else {
         uint32_t j = 0;
         while (j < n) {
@@ -433,6 +469,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     float2 *twl = fb + (size_t)geo.G * geo.W;                 // radix-4 layer twiddles (< W entries), staged once
     float *tapl = reinterpret_cast<float *>(twl + geo.W);     // FIR taps (T floats, padded to a multiple of 4)
     float *lut = tapl + ((geo.T + 3) & ~3u);                  // 8-bit unpack table
+    // shared-FIR mode (overlapping windows): every decimated output of the tile once + its truncated variant
+    float2 *dec = reinterpret_cast<float2 *>(lut + 256);
+    float2 *trc = dec + ((geo.G - 1) * geo.S + geo.W);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
@@ -546,6 +585,52 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
         const uint32_t n_out = g_cnt << logW;
         const uint32_t log_width = 2 * geo.layers;   // width = W / base_len = 4^layers
+        // Overlapping windows (S < W): the same decimated sample q sits in W/S windows.  Its value is
+        // the same in all of them except the one where it falls in the truncated tail, and
+        // that truncated value is a prefix of the same chain.  So compute each q ONCE (full chain +
+        // snapshot) and let the windows gather — W/S times less FIR work than per-window evaluation.
+        // Valid when a sample is truncated in at most one window: ntrunc <= S.
+        const uint32_t c_half = T - T / 2;
+        const uint32_t ntrunc = c_half ? (c_half + D - 1) / D - 1 : 0;
+        // compile-time for shape-specialised kernels (so only ONE FIR variant is instantiated and the long
+        // unrolled chain stays in registers), a wave-uniform runtime flag for the generic ones
+        bool shared;
+        if constexpr (GeoT::kFixed) shared = GeoT::kShared; else shared = HAS_FIR && S < W && ntrunc <= S && !(P.dbg & 2);
+        if constexpr (!GeoT::kFixed || GeoT::kShared) if (shared) {
+            const uint32_t Q = (g_cnt - 1) * S + W;
+            for (uint32_t qi = tid; qi < Q; qi += NT) {
+                uint32_t jmax = T;
+                if (qi + ntrunc >= W) {                      // may be in the truncated tail of window g
+                    const uint32_t g = (qi - (W - ntrunc)) / S, k = qi - g * S;
+                    if (k < W && g < g_cnt) { const uint32_t jm = (W - k) * D + T / 2; if (jm < T) jmax = jm; }
+                }
+                const float2 *rowp = raw + (size_t)(qi + geo.a0) * Dp;
+                float accr = 0.f, acci = 0.f;
+                float2 snap = make_float2(0.f, 0.f);
+                if constexpr (GeoT::kFixed) {
+                    fir_span<false, GeoT, true>(geo, rowp, geo.b0, 0, T, jmax, tapl, accr, acci, &snap);
+                } else {
+                    fir_span<false>(geo, rowp, geo.b0, 0, T, T, tapl, accr, acci);
+                    if (jmax < T) {                          // generic kernels: second, predicated pass for the prefix
+                        float sr = 0.f, si = 0.f;
+                        fir_span<true>(geo, rowp, geo.b0, 0, T, jmax, tapl, sr, si);
+                        snap = make_float2(sr, si);
+                    }
+                }
+                dec[qi] = make_float2(accr, acci);
+                if (jmax < T) trc[qi] = snap;
+            }
+            __syncthreads();
+            for (uint32_t o = tid; o < n_out; o += NT) {
+                const uint32_t g = o >> logW, k = o & (W - 1);
+                const uint32_t qi = g * S + k;
+                const bool tr = (W - k) * D + T / 2 < T;
+                const float2 v = tr ? trc[qi] : dec[qi];
+                const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
+            }
+        }
+        if constexpr (!GeoT::kFixed || !GeoT::kShared) if (!shared)
         for (uint32_t o = tid; o < n_out; o += NT) {
             const uint32_t g = o >> logW, k = o & (W - 1);
             const uint32_t q = g * S + k;

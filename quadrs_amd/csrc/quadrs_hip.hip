@@ -278,7 +278,8 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     if (elems < min_elems) elems = min_elems;
     elems = (elems + 1) & ~1ull;                      // keep fb 16-byte aligned
     if (raw_elems) *raw_elems = (uint32_t)elems;
-    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + W * 8 + ((T + 3) & ~3ull) * 4 + 256 * 4);   // raw tile + FFT buffer + twiddles + taps + 8-bit LUT
+    uint64_t shared_fir = (T && S < W) ? 2 * ((uint64_t)(G - 1) * S + W) * 8 : 0;   // dec[] + trc[] of the shared-FIR mode
+    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + W * 8 + ((T + 3) & ~3ull) * 4 + 256 * 4 + shared_fir);   // raw tile + FFT buffer + twiddles + taps + 8-bit LUT (+ shared FIR)
 }
 
 constexpr size_t kLdsMax = 160 * 1024;
