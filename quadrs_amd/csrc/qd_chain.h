@@ -364,7 +364,47 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                     acci = acci + x.y * hh;
                 }
             }
-        } else if (n > 256 && GeoT::kFirBlock >= 8) {      // (kFirBlock 4 = a build that prefers the small-block pipelined form)
+        } else if (n > 256 && GeoT::kFirBlock >= 8 && D % 8 == 0 && b % 8 == 0 && n % 8 == 0 && (!SNAP || (geo.T % D) % 8 == 0) && !PRED) {
+            // very long filters: ROLLED and software-pipelined.  8-tap blocks never straddle an LDS row
+            // (D, b multiples of 8); two register sets ping-pong so that block k+1's LDS reads (8 samples
+            // + two broadcast ds_read_b128 of taps) are in flight while block k is accumulated; a lane's
+            // jmax (multiple of 8 here) can only be hit at a block boundary, so the snapshot is one
+            // compare + two selects per candidate block.  Fully unrolling 400-500 taps instead makes
+            // the register allocator spill hundreds of values.
+            const uint32_t nblk = n / 8;
+            float2 xa[8], xb[8]; float4 ha[2], hb[2];
+            auto load_blk = [&](uint32_t blk, float2 *x, float4 *hh) {
+                const uint32_t t = b + blk * 8;
+                const float2 *pp = rowp + (t / D) * Dp + (t % D);          // wave-uniform offset
+#pragma unroll
+                for (int i2 = 0; i2 < 8; ++i2) x[i2] = pp[i2];
+                const float4 *hp = reinterpret_cast<const float4 *>(h + blk * 8);
+                hh[0] = hp[0]; hh[1] = hp[1];
+            };
+            auto mac_blk = [&](uint32_t blk, const float2 *x, const float4 *hh) {
+                const uint32_t jj = j0 + blk * 8;
+                if (SNAP && jj >= geo.T / 2 + D && jj < geo.T && ((jj - geo.T / 2) % D) == 0) {   // wave-uniform
+                    if (jmax == jj) { snapr = accr; snapi = acci; }
+                }
+                accr = accr + x[0].x * hh[0].x; acci = acci + x[0].y * hh[0].x;
+                accr = accr + x[1].x * hh[0].y; acci = acci + x[1].y * hh[0].y;
+                accr = accr + x[2].x * hh[0].z; acci = acci + x[2].y * hh[0].z;
+                accr = accr + x[3].x * hh[0].w; acci = acci + x[3].y * hh[0].w;
+                accr = accr + x[4].x * hh[1].x; acci = acci + x[4].y * hh[1].x;
+                accr = accr + x[5].x * hh[1].y; acci = acci + x[5].y * hh[1].y;
+                accr = accr + x[6].x * hh[1].z; acci = acci + x[6].y * hh[1].z;
+                accr = accr + x[7].x * hh[1].w; acci = acci + x[7].y * hh[1].w;
+            };
+            load_blk(0, xa, ha);
+            for (uint32_t blk = 0; blk < nblk; blk += 2) {
+                if (blk + 1 < nblk) load_blk(blk + 1, xb, hb);
+                mac_blk(blk, xa, ha);
+                if (blk + 1 < nblk) {
+                    if (blk + 2 < nblk) load_blk(blk + 2, xa, ha);
+                    mac_blk(blk + 1, xb, hb);
+                }
+            }
+        } else if (n > 256 && GeoT::kFirBlock >= 8) {
             // very long filters: a ROLLED loop over LDS rows (D taps each) with an 8-tap inner unroll —
             // fully unrolling 400-500 taps blows the register allocator up.  A lane's jmax can only be
             // reached at ONE column of a row (column T % D, see is_snap), so the snapshot check is
