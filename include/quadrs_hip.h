@@ -46,7 +46,12 @@ typedef enum { QD_MEM_HOST = 0, QD_MEM_DEVICE = 1 } qd_mem;
 typedef enum {
     QD_EPI_NORMS_F32 = 0,    /* W f32: hypot(re,im) in fftshift order (src/fft.rs:48-53) */
     QD_EPI_GLYPH_U8 = 1,     /* W u8: 0=' ' 1..7='▁'..'▇' 8='█' 255=reference would panic (src/fft.rs:54-60) */
-    QD_EPI_BUCKET2_U8 = 2    /* 1 u8: freq_levels digit (src/fft.rs:95-97) */
+    QD_EPI_BUCKET2_U8 = 2,   /* 1 u8: freq_levels digit (src/fft.rs:95-97) */
+    QD_EPI_CF32_BLOCKS = 3   /* the write sink (do_write, src/lib.rs:199-210): no FFT; a "window" is one full
+                                LowPass::read_at block of `width` decimated samples (0x1000 for do_write, a power
+                                of two), `stride` is ignored, the output is width qd_c32 per block with the block's
+                                own tail truncation.  n_windows counts the FULL blocks, floor((n-T)/(width*D));
+                                the ragged end of the stream is left to qd_lowpass_block.  Needs has_lowpass. */
 } qd_epilogue;
 
 const char *qd_last_error(void);

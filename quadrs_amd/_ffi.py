@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("QD_LIB_PATH") or os.path.join(_HERE, "libquadrs_hip.s
 OK, ERR_INVALID, ERR_PANIC, ERR_SHORT, ERR_HIP, ERR_UNSUPPORTED = range(6)
 FMT_CF32, FMT_CS8, FMT_CU8, FMT_CS16 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
-EPI_NORMS_F32, EPI_GLYPH_U8, EPI_BUCKET2_U8 = 0, 1, 2
+EPI_NORMS_F32, EPI_GLYPH_U8, EPI_BUCKET2_U8, EPI_CF32_BLOCKS = 0, 1, 2, 3
 
 # every symbol include/quadrs_hip.h declares
 SYMBOLS = [

@@ -457,15 +457,44 @@ void run_iter_sink(const Samples &s, const Op &sink) {
     if (sink.kind == OP_BUCKET) printf("%s\n", digits.c_str());
 }
 
-// do_write (src/lib.rs:178-213)
-void do_write(const Samples &s, bool overwrite, const std::string &prefix) {
+// do_write (src/lib.rs:178-213).  When the chain is  from [shift] lowpass  the full 0x1000-sample
+// read_at blocks come from ONE fused plan (QD_EPI_CF32_BLOCKS); the ragged end of the stream — where
+// every read_at has its own `valid` — and any other chain go through the block iterator.
+void do_write(const Samples &s, bool overwrite, const std::string &prefix, const ChainSpec *cs) {
     if (prefix == "-") bail("not implemented");
     std::string fn = prefix + ".sr" + std::to_string(s.sample_rate()) + ".cf32";
     int flags = O_WRONLY | (overwrite ? O_CREAT : (O_CREAT | O_EXCL));
     int fd = open(fn.c_str(), flags, 0644);
     if (fd < 0) bail(std::string(strerror(errno)) + " (os error " + std::to_string(errno) + ")");
+    uint64_t off = 0, len;
+    try { len = s.len(); } catch (...) { close(fd); throw; }
+    if (cs && cs->fusable && cs->lowpass && !getenv("QUADRS_HIP_NO_FUSE")) {
+        std::vector<uint8_t> data = slurp(cs->src->filename);
+        qd_chain_desc d{};
+        d.struct_size = sizeof d;
+        d.format = cs->src->format; d.sample_rate = cs->src->sample_rate;
+        d.n_samples = data.size() / qd_pair_bytes(cs->src->format);
+        if (cs->shift) { d.has_shift = 1; d.shift_hz = cs->shift->shift; }
+        d.has_lowpass = 1; d.lowpass_hz = cs->lowpass->lp_freq; d.decimate = cs->lowpass->decimate; d.taps = cs->lowpass->size;
+        d.width = 0x1000; d.stride = 0x1000; d.epilogue = QD_EPI_CF32_BLOCKS;
+        qd_plan *plan = nullptr;
+        int rc = qd_plan_create(&d, &plan);
+        if (rc == QD_OK) {
+            qd_plan_info info;
+            qd_check(qd_plan_get_info(plan, &info), "plan info");
+            if (info.n_windows) {
+                std::vector<qd_c32> out(info.n_windows * 0x1000);
+                rc = qd_plan_run(plan, data.data(), QD_MEM_HOST, 0, d.n_samples, 0, info.n_windows, out.data(), QD_MEM_HOST, nullptr);
+                if (rc == QD_OK) {
+                    if (write(fd, out.data(), out.size() * sizeof(qd_c32)) < 0) { qd_plan_destroy(plan); close(fd); bail("write failed"); }
+                    off = info.n_windows * 0x1000;
+                }
+            }
+            qd_plan_destroy(plan);
+        }
+        if (rc != QD_OK && rc != QD_ERR_UNSUPPORTED) { close(fd); qd_check(rc, "fused write"); }
+    }
     std::vector<qd_c32> buf(0x1000);
-    uint64_t off = 0, len = s.len();
     while (off < len) {
         size_t rd;
         try { rd = s.read_at(off, buf.data(), buf.size()); } catch (...) { close(fd); throw; }
@@ -534,7 +563,7 @@ int main(int argc, char **argv) {
                 break;
             case OP_WRITE:
                 if (!samples) bail("write requires an input");
-                do_write(*samples, op.overwrite, op.prefix);
+                do_write(*samples, op.overwrite, op.prefix, chain_clean ? &cs : nullptr);
                 break;
             }
         }

@@ -80,6 +80,10 @@ struct ChainParams {
     unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
     const uint64_t *row_offsets; // take_fft (src/ffts.rs:59-60): window w starts at row_offsets[w] (generic kernels, G = 1)
     const float *window;         // take_fft windowing (src/ffts.rs:64-68): sample k of a window is scaled by window[k]
+    uint32_t blk_len;            // length B of the read_at block the truncation is relative to (== W except QD_EPI_CF32_BLOCKS)
+    uint32_t blk_sub_mask;       // QD_EPI_CF32_BLOCKS: (B / W) - 1, sub-windows per block minus one
+    uint32_t tile_extra;         // QD_EPI_CF32_BLOCKS: max(0, c - D) more raw samples per tile (a tile that ends inside a
+                                 // block has untruncated outputs whose taps reach past W*D + T); 0 otherwise
     // ---- geometry (only DynGeo reads these; FixedGeo has them as constants)
     uint32_t W, logW, S, D, T, G;
     uint32_t Dp;               // LDS row pitch: D + 1 if D even else D
@@ -168,6 +172,7 @@ __device__ __forceinline__ TileGeo tile_geo(const ChainParams &P, const GeoT &ge
         if (P.row_offsets && g.valid) g.n_start = P.row_offsets[g.w0 - P.out_window0];   // irregular rows (take_fft), uniform load
     }
     g.tile_raw = g.valid ? (g.g_cnt - 1) * geo.S * geo.D + geo.W * geo.D + geo.T : 0u;   // B*D + T (src/filter.rs:68)
+    if constexpr (!GeoT::kFixed) { if (g.valid) g.tile_raw += P.tile_extra; }
     g.r0 = g.n_start / ROW;
     g.rel0 = (int32_t)(int64_t)(g.r0 * ROW - g.n_start);
     g.n_rows = (uint32_t)((g.tile_raw - g.rel0 + ROW - 1) / ROW);
@@ -625,6 +630,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
         const uint32_t n_out = g_cnt << logW;
         const uint32_t log_width = 2 * geo.layers;   // width = W / base_len = 4^layers
+        const bool cf32_out = !GeoT::kFixed && P.epi == 3;   // QD_EPI_CF32_BLOCKS (generic kernels only)
         // Overlapping windows (S < W): the same decimated sample q sits in W/S windows.  Its value is
         // the same in all of them except the one where it falls in the truncated tail, and
         // that truncated value is a prefix of the same chain.  So compute each q ONCE (full chain +
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         // compile-time for shape-specialised kernels (so only ONE FIR variant is instantiated and the long
         // unrolled chain stays in registers), a wave-uniform runtime flag for the generic ones
         bool shared;
-        if constexpr (GeoT::kFixed) shared = GeoT::kShared; else shared = HAS_FIR && S < W && ntrunc <= S && !(P.dbg & 2);
+        if constexpr (GeoT::kFixed) shared = GeoT::kShared; else shared = HAS_FIR && S < W && ntrunc <= S && !(P.dbg & 2) && P.epi != 3;
         if constexpr (!GeoT::kFixed || GeoT::kShared) if (shared) {
             const uint32_t Q = (g_cnt - 1) * S + W;
             for (uint32_t qi = tid; qi < Q; qi += NT) {
@@ -676,8 +682,10 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             const uint32_t q = g * S + k;
             float accr = 0.f, acci = 0.f;
             if (HAS_FIR && !(P.dbg & 2)) {
-                // jmax(k) = min(T, valid - (k*D + c)) with valid = W*D + T (full read)
-                uint32_t jmax = (W - k) * D + T / 2;
+                // jmax(k) = min(T, valid - (k*D + c)) with valid = B*D + T (full read of a block of B outputs;
+                // B == W for the FFT sinks, B = 0x1000 > W for the write sink whose tiles are sub-blocks)
+                const uint32_t kb = cf32_out ? (((uint32_t)(w0 + g)) & P.blk_sub_mask) * W + k : k;
+                uint32_t jmax = ((cf32_out ? P.blk_len : W) - kb) * D + T / 2;
                 if (jmax > T) jmax = T;
                 const float2 *rowp = raw + (size_t)(q + geo.a0) * Dp;
                 if (geo.T_fast == T || __all(jmax == T)) {
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             }
             // bitreversed_transpose::<4>(base_len, ..): out[y + rev(x)*base] = in[x + y*width]
             const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
-            const uint32_t pos = yy + (rev4(xx, geo.layers) << geo.log_base);
+            const uint32_t pos = cf32_out ? k : yy + (rev4(xx, geo.layers) << geo.log_base);   // write sink: natural order
             fb[(g << logW) + pos] = make_float2(accr, acci);
         }
         QD_STAMP_AT(2);
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         QD_STAMP_AT(3);
 
         // ---------------- phase 3: FFT (rustfft Radix4: base butterflies, then radix-4 layers)
-        if (!(P.dbg & 4)) {
+        if (!(P.dbg & 4) && !cf32_out) {
             const uint32_t base = geo.base_len;
             const uint32_t log_tpw = logW - geo.log_base;   // base tasks per window = W / base
             const uint32_t n_task = g_cnt << log_tpw;
@@ -764,7 +772,11 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
         // ---------------- phase 4: fftshift + norm + epilogue (out index is tile base + o: coalesced)
         const uint64_t wrel = w0 - P.out_window0;
-        if (P.epi == 2) {
+        if (cf32_out) {
+            // do_write / LowPass::read_at output (src/lib.rs:206-209): the decimated cf32 samples themselves
+            float2 *outc = reinterpret_cast<float2 *>(P.out) + (wrel << logW);
+            for (uint32_t o = tid; o < n_out; o += NT) outc[o] = fb[o];
+        } else if (P.epi == 2) {
             // freq_levels (src/fft.rs:95-97): sequential f32 sums of |X[k]| over each half
             float *nb = reinterpret_cast<float *>(raw);       // raw tile is dead now
             for (uint32_t o = tid; o < n_out; o += NT) nb[o] = norm_ref(fb[o]);

@@ -293,6 +293,8 @@ struct qd_plan {
     int device = 0;
     bool has_shift = false, has_fir = false;
     uint32_t W = 0, logW = 0, S = 0, D = 1, T = 0;
+    uint32_t blk_len = 0, blk_subs = 1;     // QD_EPI_CF32_BLOCKS: read_at block length and sub-windows per block
+    uint32_t tile_extra = 0;                // ... and extra raw samples per tile (see ChainParams)
     uint64_t dec_len = 0, n_windows = 0, out_rate = 0;
     double ratio = 0.0;
     std::vector<float> taps_h;
@@ -327,6 +329,7 @@ uint64_t out_bytes_per_window(const qd_plan *p) {
     switch (p->d.epilogue) {
     case QD_EPI_NORMS_F32: return (uint64_t)p->W * 4;
     case QD_EPI_GLYPH_U8: return p->W;
+    case QD_EPI_CF32_BLOCKS: return (uint64_t)p->blk_len * 8;
     default: return 1;
     }
 }
@@ -385,6 +388,8 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
     P.out = out_d;
     P.row_offsets = p->row_offsets_d; P.window = p->window_d;
+    P.blk_len = p->blk_len ? p->blk_len : p->W; P.blk_sub_mask = p->blk_subs - 1;
+    P.tile_extra = p->tile_extra;
     if (const char *e = getenv("QD_DEBUG_SKIP")) P.dbg = (uint32_t)atoi(e);   // timing-only ablation, never set in tests/bench
 #ifdef QD_STAMP
     static unsigned long long *stamps_d = nullptr;
@@ -503,11 +508,20 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->has_shift = d.has_shift != 0;
     p->has_fir = d.has_lowpass != 0;
     p->W = (uint32_t)d.width; p->logW = ilog2(d.width); p->S = (uint32_t)d.stride;
+    if (d.epilogue == QD_EPI_CF32_BLOCKS) {          // tiles are sub-blocks of <= 256 outputs of a read_at block of d.width
+        p->blk_len = (uint32_t)d.width;
+        p->W = p->blk_len < 256 ? p->blk_len : 256;
+        p->logW = ilog2(p->W); p->S = p->W;
+        p->blk_subs = p->blk_len / p->W;
+        const uint32_t c = (uint32_t)(d.taps - d.taps / 2);
+        p->tile_extra = c > d.decimate ? c - (uint32_t)d.decimate : 0;
+    }
     p->D = p->has_fir ? (uint32_t)d.decimate : 1;
     p->T = p->has_fir ? (uint32_t)d.taps : 0;
     p->dec_len = len; p->out_rate = rate;
-    uint64_t lim = len - d.width;
-    if (d.epilogue == QD_EPI_BUCKET2_U8) p->n_windows = lim / d.stride;                 // src/fft.rs:86
+    uint64_t lim = len >= d.width ? len - d.width : 0;
+    if (d.epilogue == QD_EPI_CF32_BLOCKS) p->n_windows = (d.n_samples - d.taps) / (d.width * d.decimate);   // full read_at blocks
+    else if (d.epilogue == QD_EPI_BUCKET2_U8) p->n_windows = lim / d.stride;            // src/fft.rs:86
     else p->n_windows = lim == 0 ? 0 : (lim - 1) / d.stride + 1;                        // src/fft.rs:28,65
     p->ratio = p->has_shift ? qd_shift_ratio(d.shift_hz, d.sample_rate) : 0.0;
 
@@ -518,20 +532,21 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
 
     // tile geometry: a shape-specialised kernel dictates G; otherwise pick G for LDS / lane use
     uint32_t G = 1, raw_elems = 0;
-    if (lds_for(1, p->W, p->S, p->D, p->T, &raw_elems) > kLdsMax)
+    const uint32_t T_lds = p->T + p->tile_extra;     // LDS sizing sees the extended tile
+    if (lds_for(1, p->W, p->S, p->D, T_lds, &raw_elems) > kLdsMax)
         return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
                     (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
-    p->fixed = p->has_fir ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
+    p->fixed = (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS) ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
     if (p->fixed) {
         G = p->fixed->G;
         p->nt = p->fixed->nt;
     } else {
-        while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 40 * 1024) G *= 2;
-        while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, p->T, nullptr) <= 36 * 1024) G *= 2;
+        while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr) <= 40 * 1024) G *= 2;
+        while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr) <= 36 * 1024) G *= 2;
         if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
     }
     p->geo.G = G;
-    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, p->T, &raw_elems);
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems);
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
@@ -580,7 +595,8 @@ int qd_plan_create(const qd_chain_desc *desc, qd_plan **out) {
     if (desc->struct_size != sizeof(qd_chain_desc)) return fail(QD_ERR_INVALID, "qd_chain_desc size mismatch");
     const qd_chain_desc &d = *desc;
     if (d.format < 0 || d.format > 3) return fail(QD_ERR_INVALID, "unknown format %d", d.format);
-    if (d.epilogue < 0 || d.epilogue > 2) return fail(QD_ERR_INVALID, "unknown epilogue %d", d.epilogue);
+    if (d.epilogue < 0 || d.epilogue > 3) return fail(QD_ERR_INVALID, "unknown epilogue %d", d.epilogue);
+    if (d.epilogue == QD_EPI_CF32_BLOCKS && !d.has_lowpass) return fail(QD_ERR_INVALID, "QD_EPI_CF32_BLOCKS needs a lowpass in the chain");
     if (!is_pow2(d.width))
         return fail(QD_ERR_PANIC, "Radix4 requires a power-of-two width (rustfft API contract), got %llu", (unsigned long long)d.width);
     if (d.width > (1u << 20)) return fail(QD_ERR_UNSUPPORTED, "width too large");
@@ -601,7 +617,7 @@ int qd_plan_create(const qd_chain_desc *desc, qd_plan **out) {
         len = 1 + (len - d.taps) / d.decimate;     // LowPass::len, src/filter.rs:47
         rate = rate / d.decimate;                  // src/filter.rs:51
     }
-    if (len < d.width) return fail(QD_ERR_PANIC, "len %llu < width %llu: u64 underflow at src/fft.rs:28,86",
+    if (d.epilogue != QD_EPI_CF32_BLOCKS && len < d.width) return fail(QD_ERR_PANIC, "len %llu < width %llu: u64 underflow at src/fft.rs:28,86",
                                    (unsigned long long)len, (unsigned long long)d.width);
     qd_plan *p = new qd_plan();
     p->d = d;
@@ -631,8 +647,8 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->decimated_len = p->dec_len;
     info->out_sample_rate = p->out_rate;
     info->out_bytes_per_window = out_bytes_per_window(p);
-    info->raw_per_window = (uint64_t)p->W * p->D + p->T;
-    info->raw_step = (uint64_t)p->S * p->D;
+    info->raw_per_window = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
+    info->raw_step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D;
     info->ratio = p->ratio;
     info->tile_windows = p->geo.G;
     info->threads = (uint32_t)p->nt;
@@ -649,9 +665,10 @@ int qd_plan_get_taps(const qd_plan *p, float *taps, size_t cap) {
 
 int qd_plan_src_range(const qd_plan *p, uint64_t first_window, uint64_t n_windows, uint64_t *first, uint64_t *count) {
     if (!p || !first || !count) return fail(QD_ERR_INVALID, "NULL argument");
-    if (n_windows == 0) { *first = first_window * p->S * p->D; *count = 0; return QD_OK; }
-    *first = first_window * p->S * p->D;
-    *count = (n_windows - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
+    const uint64_t step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D;
+    const uint64_t rpw = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
+    *first = first_window * step;
+    *count = n_windows ? (n_windows - 1) * step + rpw : 0;
     return QD_OK;
 }
 
@@ -672,6 +689,7 @@ int qd_plan_last_kernel_ms(qd_plan *p, float *ms) {
 int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint64_t src_count,
                 uint64_t first_window, uint64_t n_windows, void *out, int out_mem, void *stream) {
     if (!p || !src || !out) return fail(QD_ERR_INVALID, "NULL argument");
+    const uint64_t subs = p->blk_subs;          // 1 except QD_EPI_CF32_BLOCKS (API windows are whole blocks)
     if (first_window + n_windows > p->n_windows)
         return fail(QD_ERR_SHORT, "windows [%llu,+%llu) exceed the sink's loop (%llu windows)", (unsigned long long)first_window,
                     (unsigned long long)n_windows, (unsigned long long)p->n_windows);
@@ -679,13 +697,14 @@ int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, ui
     std::lock_guard<std::mutex> lock(p->mu);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (src_mem == QD_MEM_DEVICE && out_mem == QD_MEM_DEVICE)
-        return launch_chain(p, src, src_first, src_count, first_window, n_windows, first_window, out, st);
+        return launch_chain(p, src, src_first, src_count, first_window * subs, n_windows * subs, first_window * subs, out, st);
     if (src_mem != QD_MEM_HOST || out_mem != QD_MEM_HOST)
         return fail(QD_ERR_UNSUPPORTED, "mixed host/device buffers are not supported; use both host or both device");
 
     // host-resident stream: chunked, double-buffered H2D / kernel / D2H
     const int bps = bps_of(p->d.format);
-    const uint64_t obw = out_bytes_per_window(p);
+    const uint64_t obw = out_bytes_per_window(p) / subs;      // per kernel window (a sub-block for QD_EPI_CF32_BLOCKS)
+    first_window *= subs; n_windows *= subs;                  // from here on: kernel-window units
     const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
     const uint64_t target_bytes = 64ull << 20;
     uint64_t cw = target_bytes / (step * bps ? step * bps : 1);

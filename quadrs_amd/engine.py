@@ -153,6 +153,8 @@ class Plan:
             return (n_windows, self.width), np.float32
         if self.epilogue == _ffi.EPI_GLYPH_U8:
             return (n_windows, self.width), np.uint8
+        if self.epilogue == _ffi.EPI_CF32_BLOCKS:
+            return (n_windows * self.width, 2), np.float32
         return (n_windows,), np.uint8
 
     def run_host(self, data, first_window=0, n_windows=None, src_first=0):

@@ -97,13 +97,15 @@ def test_bucket_and_default_flags(cli, oracle, fsk):
 
 
 @pytest.mark.gpu
-def test_write_after_lowpass_matches_reference_bytes(cli, oracle, tmp_path):
+@pytest.mark.parametrize("nofuse", ["", "1"])
+def test_write_after_lowpass_matches_reference_bytes(cli, oracle, tmp_path, nofuse):
     """do_write (src/lib.rs:178-213): same bytes, then the reference's end-of-stream assert as exit 1."""
     rng = np.random.default_rng(7)
     x = (rng.standard_normal((3 * 4096 * 4 + 40 + 100, 2)) * 0.05).astype(np.float32)
     src = tmp_path / "in.sr1M.cf32"
     src.write_bytes(x.tobytes())
-    r = run(cli, "from", str(src), "lowpass", "-decimate", "4", "100000", "write", "out", cwd=str(tmp_path))
+    r = run(cli, "from", str(src), "lowpass", "-decimate", "4", "100000", "write", "out", cwd=str(tmp_path),
+            env={"QUADRS_HIP_NO_FUSE": nofuse} if nofuse else None)
     rc, n, samples = oracle.Chain.from_bytes(x.tobytes(), 0, 1_000_000).lowpass(100_000, 4, 40).do_write(4 * 4096)
     assert rc == 2 and r.returncode == 1 and b"short read" in r.stderr        # LowPass::len over-reports by one
     got = np.frombuffer((tmp_path / "out.sr250000.cf32").read_bytes(), dtype=np.float32).reshape(-1, 2)

@@ -274,6 +274,37 @@ def test_glyph_and_bucket_epilogues(engine, oracle, fsk):
         assert np.array_equal(got2, ref2) and 0.2 < ref2.mean() < 0.8
 
 
+@pytest.mark.parametrize("fmt,D,T,B,shift", [(0, 4, 40, 4096, None), (0, 8, 40, 4096, 280000), (1, 16, 400, 4096, 280000),
+                                              (0, 3, 10, 64, None), (0, 32, 200, 1024, -100000)])
+def test_fused_write_blocks(engine, oracle, fmt, D, T, B, shift):
+    """N1: QD_EPI_CF32_BLOCKS == LowPass::read_at over full blocks of B outputs (do_write, src/lib.rs:199-210),
+    including each block's own tail truncation."""
+    n_blocks = 3
+    N = n_blocks * B * D + T + B * D // 2          # three full blocks + a ragged remainder the plan leaves alone
+    rng = np.random.default_rng(B + D)
+    data = _to_format(_signal(rng, N), fmt)
+    ch = oracle.Chain.from_bytes(data, fmt, 21_000_000)
+    if shift is not None:
+        ch = ch.shift(shift)
+    ch = ch.lowpass(500_000, D, T)
+    p = engine.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=(500_000, D, T), width=B, epilogue=engine.EPI_CF32_BLOCKS)
+    assert p.n_windows == n_blocks and p.info.out_bytes_per_window == B * 8
+    got = p.run_host(data)
+    ref = np.concatenate([ch.read_at(b * B, B)[1] for b in range(n_blocks)])
+    assert all(ch.read_at(b * B, B)[0] == B for b in range(n_blocks))
+    err = complex_ulp_err(ref, got)
+    exact = (ref.view(np.uint32) == got.view(np.uint32)).all(axis=1).mean()
+    assert err.max() <= (1.0 if shift is not None else 0.0) + 1e-9 and exact >= 0.999, (err.max(), exact)
+    # the truncated tail of a block really differs from the untruncated continuation
+    cont = ch.read_at(B - 8, 16)[1][:8]
+    assert not bits_equal(cont[-1:], ref[B - 1:B]) or T // 2 <= D
+    # block sub-range + slab
+    first, count = p.src_range(1, 2)
+    bps = {0: 8, 1: 2, 2: 2, 3: 4}[fmt]
+    part = p.run_host(data[first * bps:(first + count) * bps], 1, 2, src_first=first)
+    assert bits_equal(part, got[B:3 * B])
+
+
 def test_window_subranges_and_slabs_concatenate(engine, oracle):
     """§8(e): windows are independent; a slab [src_first, ...) + absolute indices reproduces the
     whole-stream run bit for bit — including seams and an unaligned (odd) slab start."""
