@@ -1,0 +1,136 @@
+"""GPU robustness: far-offset slabs (second-order NCO kernels), device-memory fine-grained calls,
+concurrent use of one plan, degenerate sizes."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from util import bits_equal, complex_ulp_err, ulp_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _norms_close(ref, got):
+    exact = (ref.view(np.uint32) == got.view(np.uint32)).mean()
+    scale = ulp_of(ref.max(axis=-1, keepdims=True)).astype(np.float64)
+    worst = (np.abs(ref.astype(np.float64) - got.astype(np.float64)) / scale).max()
+    return exact, worst
+
+
+@pytest.mark.parametrize("lp,W,S", [((2_000_000, 16, 40), 128, 128),     # cfg2 shape  -> FixedGeo, NCO order 2
+                                    ((200_000, 32, 200), 128, 128),      # cfg3' shape -> FixedGeo, NCO order 2
+                                    ((200_000, 32, 400), 64, 16),        # README FSK shape (shared FIR), order 2
+                                    ((700_000, 10, 24), 16, 5)])         # generic kernel, order 2
+def test_far_offset_slab_uses_second_order_nco(engine, oracle, lp, W, S):
+    """A slab deep inside a 2^34-sample stream (cfg5 territory): |place| ~ 7e8 rad, where the NCO needs
+    its second-order term; every window is checked against the oracle evaluated at absolute indices."""
+    fc, D, T = lp
+    N = 1 << 34
+    p = engine.Plan(0, 21_000_000, N, shift_hz=280000, lowpass=lp, width=W, stride=S)
+    w0 = (1 << 33) // (S * D) + 12345
+    nwin = 24
+    first, count = p.src_range(w0, nwin)
+    rng = np.random.default_rng(W * 7 + S)
+    x = (rng.standard_normal((count, 2)) * 0.03).astype(np.float32)
+    got = p.run_host(x.tobytes(), w0, nwin, src_first=first)
+    ratio = oracle.shift_ratio(280000, 21_000_000)
+    taps = oracle.taps(fc, 21_000_000, T)
+    ref = np.empty_like(got)
+    for i in range(nwin):
+        a = (w0 + i) * S * D - first
+        raw = oracle.shift_apply(x[a:a + W * D + T], (w0 + i) * S * D, ratio)
+        k, dec = oracle.lowpass_block(taps, D, raw)
+        assert k == W
+        y = oracle.fft(dec)
+        ref[i] = oracle.norm(y)[np.r_[W // 2:W, 0:W // 2]]
+    exact, worst = _norms_close(ref, got)
+    assert exact >= 0.999 and worst <= 4.0, (exact, worst)
+
+
+def test_fine_grained_calls_on_device_memory(engine, oracle):
+    import torch
+    from quadrs_amd import _ffi
+    L = _ffi.lib()
+    rng = np.random.default_rng(3)
+    # unpack
+    raw8 = rng.integers(0, 256, 2 * 5000, dtype=np.uint8)
+    d_in = torch.from_numpy(raw8).cuda()
+    d_out = torch.empty(5000, 2, dtype=torch.float32, device="cuda")
+    _ffi.check(L.qd_unpack(_ffi.FMT_CS8, C.c_void_p(d_in.data_ptr()), 5000, C.c_void_p(d_out.data_ptr()), _ffi.MEM_DEVICE))
+    torch.cuda.synchronize()
+    assert bits_equal(d_out.cpu().numpy(), oracle.unpack(oracle.FMT_CS8, raw8.tobytes()))
+    # shift in place
+    x = (rng.standard_normal((30_000, 2)) * 0.1).astype(np.float32)
+    ratio = engine.shift_ratio(-123_456, 2_000_000)
+    d_x = torch.from_numpy(x).cuda()
+    _ffi.check(L.qd_shift(C.c_void_p(d_x.data_ptr()), 30_000, 777_777_777, ratio, _ffi.MEM_DEVICE))
+    assert complex_ulp_err(oracle.shift_apply(x, 777_777_777, ratio), d_x.cpu().numpy()).max() <= 1.0
+    # lowpass block
+    taps = oracle.taps(1000, 16000, 64)
+    raw = rng.standard_normal((200 * 8 + 64, 2)).astype(np.float32)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_dec = torch.empty(200, 2, dtype=torch.float32, device="cuda")
+    produced = C.c_size_t(0)
+    _ffi.check(L.qd_lowpass_block(taps.ctypes.data_as(C.c_void_p), 64, 8, C.c_void_p(d_raw.data_ptr()), raw.shape[0],
+                                  C.c_void_p(d_dec.data_ptr()), 200, C.byref(produced), _ffi.MEM_DEVICE))
+    assert produced.value == 200 and bits_equal(d_dec.cpu().numpy(), oracle.lowpass_block(taps, 8, raw)[1])
+    # fft batch
+    xin = rng.standard_normal((256 * 4, 2)).astype(np.float32)
+    d_xin = torch.from_numpy(xin).cuda()
+    d_n = torch.empty(4, 256, dtype=torch.float32, device="cuda")
+    _ffi.check(L.qd_fft_norm_batch(C.c_void_p(d_xin.data_ptr()), 256, 4, 256, C.c_void_p(d_n.data_ptr()), _ffi.MEM_DEVICE))
+    for i in range(4):
+        assert bits_equal(d_n[i].cpu().numpy(), oracle.norm(oracle.fft(xin[i * 256:(i + 1) * 256]))[np.r_[128:256, 0:128]])
+    # gen
+    cos = np.array([1000, -2500], dtype=np.int64)
+    d_g = torch.empty(100, 2, dtype=torch.float32, device="cuda")
+    _ffi.check(L.qd_gen(cos.ctypes.data_as(C.c_void_p), 2, 48000, 1 << 20, 100, C.c_void_p(d_g.data_ptr()), _ffi.MEM_DEVICE))
+    assert complex_ulp_err(oracle.Chain.gen([1000, -2500], 48000).read_at(1 << 20, 100)[1], d_g.cpu().numpy()).max() <= 1.0
+
+
+def test_concurrent_runs_on_one_plan(engine):
+    """Samples: Sync + Send — concurrent calls on one object are legal; the plan serialises them."""
+    rng = np.random.default_rng(11)
+    N = 400_000
+    x = (rng.standard_normal((N, 2)) * 0.05).astype(np.float32).tobytes()
+    p = engine.Plan(0, 21_000_000, N, shift_hz=280000, lowpass=(2_000_000, 16, 40), width=128)
+    want = p.run_host(x)
+    results, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            results[i] = p.run_host(x)
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors and all(bits_equal(r, want) for r in results)
+
+
+def test_degenerate_sizes(engine, oracle):
+    # exactly one admissible window minus one: len == W  ->  the strict `<` loop runs zero times
+    x = np.ones((128, 2), dtype=np.float32)
+    p = engine.Plan(0, 1000, 128, width=128)
+    assert p.n_windows == 0 and p.run_host(x.tobytes()).shape == (0, 128)
+    # len == W + 1: one window
+    x = np.arange(129 * 2, dtype=np.float32).reshape(-1, 2)
+    p = engine.Plan(0, 1000, 129, width=128)
+    got = p.run_host(x.tobytes())
+    ref, _ = oracle.Chain.from_bytes(x.tobytes(), 0, 1000).spark_fft(128, 128)
+    assert p.n_windows == 1 and bits_equal(got, ref)
+    # a stream shorter than one vector of its format (3 cs8 samples), width 1 and 2
+    b = np.array([1, 255, 128, 7, 0, 64], dtype=np.uint8).tobytes()
+    for W in (1, 2):
+        p = engine.Plan(1, 1000, 3, width=W, stride=1)
+        ref, _ = oracle.Chain.from_bytes(b, 1, 1000).spark_fft(W, 1)
+        assert bits_equal(p.run_host(b), ref)
+    # lowpass whose decimated length equals W + 1
+    n = 40 + 8 * 16
+    x = (np.random.default_rng(0).standard_normal((n, 2))).astype(np.float32)
+    ch = oracle.Chain.from_bytes(x.tobytes(), 0, 1000).lowpass(100, 8, 40)
+    assert ch.len() == 17
+    p = engine.Plan(0, 1000, n, lowpass=(100, 8, 40), width=16)
+    assert p.n_windows == 1 and bits_equal(p.run_host(x.tobytes()), ch.spark_fft(16, 16)[0])
