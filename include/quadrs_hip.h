@@ -135,7 +135,7 @@ typedef struct {
     uint32_t tile_windows;    /* windows per workgroup tile */
     uint32_t threads;         /* workgroup size */
     uint32_t lds_bytes;
-    uint32_t _pad;
+    uint32_t kernel_kind;     /* 0 generic (runtime geometry), 1 built-in shape-specialised, 2 specialised at plan time (hiprtc) */
 } qd_plan_info;
 
 int qd_plan_create(const qd_chain_desc *desc, qd_plan **plan);

@@ -51,7 +51,7 @@ def build_cli(force=False, verbose=False):
 
 def build(force=False, verbose=False, extra=()):
     if force or needs_build():
-        cmd = [hipcc()] + FLAGS + list(extra) + ["-o", OUT] + SRC
+        cmd = [hipcc()] + FLAGS + list(extra) + ["-o", OUT] + SRC + ["-lhiprtc", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -5,8 +5,14 @@
 // the f32 data path).  f64 fma() calls in the NCO are explicit and intentional.
 #pragma once
 
+#if !defined(__HIPCC_RTC__)      // hiprtc (plan-time specialisation) supplies the HIP builtins itself
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef unsigned char uint8_t; typedef signed char int8_t; typedef unsigned short uint16_t; typedef short int16_t;
+typedef unsigned int uint32_t; typedef int int32_t; typedef unsigned long long uint64_t; typedef long long int64_t;
+typedef unsigned long uintptr_t; typedef unsigned long size_t;
+#endif
 
 namespace qd {
 

@@ -5,13 +5,17 @@
 // the reference does this on the host too), lay out twiddles, build the NCO tables on the
 // device, pick the tile geometry, launch.  Per-sample work lives in qd_chain.h / qd_device.h.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
+#include <dlfcn.h>
+#include <map>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -265,6 +269,69 @@ const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t 
     return nullptr;
 }
 
+// ---- plan-time specialisation (hiprtc): any chain shape gets a FixedGeo build of the same kernel source.
+// The headers are read from <dir of this .so>/csrc (the in-tree layout); compiled modules are cached per
+// process.  QD_JIT=0 disables, QD_JIT=1 forces it for every plan; by default only streams whose chain
+// input is >= 16 MiB pay the ~0.3 s compile.
+struct JitKey {
+    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G;
+    bool operator<(const JitKey &o) const {
+        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G) < std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G);
+    }
+};
+std::mutex g_jit_mu;
+std::map<JitKey, hipFunction_t> g_jit_cache;
+
+std::string csrc_dir() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void *>(&csrc_dir), &info) || !info.dli_fname) return "";
+    std::string path(info.dli_fname);
+    size_t slash = path.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/csrc";
+}
+
+// returns nullptr (and leaves a message in *why) when specialisation is not possible
+hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
+    std::lock_guard<std::mutex> lock(g_jit_mu);
+    auto it = g_jit_cache.find(k);
+    if (it != g_jit_cache.end()) return it->second;
+    const std::string dir = csrc_dir();
+    FILE *probe = fopen((dir + "/qd_chain.h").c_str(), "r");
+    if (!probe) { *why = "kernel headers not found next to the library (" + dir + ")"; return nullptr; }
+    fclose(probe);
+    char name[512];
+    snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
+             k.S, k.D, k.T, k.G, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
+    std::string src = std::string("#include \"qd_chain.h\"\ntemplate __global__ void ") + name + "(const qd::ChainParams);\n";
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "qd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *why = "hiprtcCreateProgram failed"; return nullptr; }
+    hiprtcAddNameExpression(prog, name);
+    const std::string inc = "-I" + dir;
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str()};
+    hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, 0); if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        *why = "hiprtc: " + log.substr(0, 300);
+        hiprtcDestroyProgram(&prog);
+        return nullptr;
+    }
+    const char *lowered = nullptr;
+    hiprtcGetLoweredName(prog, name, &lowered);
+    size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hipModule_t mod; hipFunction_t fn = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess || !lowered || hipModuleGetFunction(&fn, mod, lowered) != hipSuccess) {
+        *why = "hipModuleLoadData / GetFunction failed";
+        hiprtcDestroyProgram(&prog);
+        return nullptr;
+    }
+    hiprtcDestroyProgram(&prog);
+    g_jit_cache[k] = fn;
+    return fn;
+}
+
 struct Geometry {
     uint32_t G = 1, Dp = 1, lds_raw_elems = 0;
     size_t lds_bytes = 0;
@@ -304,6 +371,8 @@ struct qd_plan {
     Geometry geo;
     chain_fn fn = nullptr, fn_unaligned = nullptr;
     const FixedEntry *fixed = nullptr;
+    hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
+    std::string jit_note;
     int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0, nt = kThreads;
     // NCO tables
     double2 *jtab_d = nullptr;
@@ -426,8 +495,13 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         P.first_window = w_begin; P.n_windows = w_count;
         const uint64_t n_tiles = (w_count + P.G - 1) / P.G;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
-        hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->nt : kThreads), p->geo.lds_bytes, st, P);
-        HIPCHK(hipGetLastError());
+        if (part == 0 && p->jit_fn && !p->row_offsets_d) {
+            void *args[] = {&P};
+            HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, kThreads, 1, 1, (unsigned)p->geo.lds_bytes, st, args, nullptr));
+        } else {
+            hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->nt : kThreads), p->geo.lds_bytes, st, P);
+            HIPCHK(hipGetLastError());
+        }
     }
     if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
 #ifdef QD_STAMP
@@ -554,12 +628,33 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->fn = p->fixed ? p->fixed->fn : pick_generic(d.format, p->nco, p->has_fir, true);
     p->fn_unaligned = pick_generic(d.format, p->nco, p->has_fir, false);
     if (!p->fn || !p->fn_unaligned) return fail(QD_ERR_UNSUPPORTED, "no kernel built for this format (QD_DEV_FAST build?)");
+    {
+        // plan-time specialisation for shapes without a built-in FixedGeo kernel
+        const char *jenv = getenv("QD_JIT");
+        const int jmode = jenv ? atoi(jenv) : -1;                       // -1 auto, 0 off, 1 force
+        const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
+        const bool want = !p->fixed && !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS &&
+                          (jmode == 1 || (jmode != 0 && in_bytes >= (16ull << 20)));
+        if (want) {
+            const uint64_t ROW = (uint64_t)kThreads * spl_of(d.format);
+            const uint64_t tile_raw = (uint64_t)(G - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
+            // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
+            const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
+            JitKey k{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, 4, kThreads,
+                     p->W, p->S, p->D, p->T, G};
+            p->jit_fn = jit_chain_kernel(k, &p->jit_note);
+        }
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->n_cu = prop.multiProcessorCount;
     int by_lds = (int)(kLdsMax / p->geo.lds_bytes);
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed && p->wg_per_cu > p->fixed->wg_per_cu) p->wg_per_cu = p->fixed->wg_per_cu;
     if (p->nt > kThreads) { int by_threads = 2048 / p->nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
+    if (p->jit_fn && p->geo.lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->geo.lds_bytes) != hipSuccess)
+            p->jit_fn = nullptr;     // fall back to the generic kernel
+    }
     for (chain_fn f : {p->fn, p->fn_unaligned}) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)p->geo.lds_bytes);
@@ -653,6 +748,7 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->tile_windows = p->geo.G;
     info->threads = (uint32_t)p->nt;
     info->lds_bytes = (uint32_t)p->geo.lds_bytes;
+    info->kernel_kind = p->jit_fn ? 2u : (p->fixed ? 1u : 0u);
     return QD_OK;
 }
 

@@ -134,3 +134,26 @@ def test_degenerate_sizes(engine, oracle):
     assert ch.len() == 17
     p = engine.Plan(0, 1000, n, lowpass=(100, 8, 40), width=16)
     assert p.n_windows == 1 and bits_equal(p.run_host(x.tobytes()), ch.spark_fft(16, 16)[0])
+
+
+@pytest.mark.parametrize("fmt,lp,W,S,shift", [(0, (1_500_000, 12, 48), 256, 256, -1_250_000),     # D not a power of two
+                                              (3, (300_000, 16, 100), 64, 32, 99_000),           # cs16, overlapping windows
+                                              (2, None, 32, 32, 5_000)])                         # cu8, no lowpass
+def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, fmt, lp, W, S, shift):
+    """hiprtc: the same kernel source with the plan's geometry as compile-time constants must give
+    the generic kernel's bits (and the oracle's)."""
+    from test_gpu_parity import _signal, _to_format, assert_norms_close
+    N = 300_000
+    data = _to_format(_signal(np.random.default_rng(W), N), fmt)
+    plans = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("QD_JIT", mode)
+        plans[mode] = engine.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=lp, width=W, stride=S)
+    assert plans["0"].info.kernel_kind == 0 and plans["1"].info.kernel_kind == 2
+    a, b = plans["0"].run_host(data), plans["1"].run_host(data)
+    assert bits_equal(a, b)
+    ch = oracle.Chain.from_bytes(data, fmt, 21_000_000).shift(shift)
+    if lp:
+        ch = ch.lowpass(*lp)
+    ref, _ = ch.spark_fft(W, S, max_windows=300)
+    assert_norms_close(ref, b[:ref.shape[0]], "jit")
