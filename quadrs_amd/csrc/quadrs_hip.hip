@@ -599,9 +599,10 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     else p->n_windows = lim == 0 ? 0 : (lim - 1) / d.stride + 1;                        // src/fft.rs:28,65
     p->ratio = p->has_shift ? qd_shift_ratio(d.shift_hz, d.sample_rate) : 0.0;
 
-    // |place| = n*|ratio| over the whole stream decides the NCO order once per plan: the second-order
-    // term e^2/2 (e ~ ulp(place)) matters once it approaches 1e-16, i.e. |place| > 2^26
-    p->nco = !p->has_shift ? 0 : ((std::fabs(p->ratio) * (double)d.n_samples > 67108864.0) ? 2 : 1);
+    // |place| = n*|ratio| over the whole stream decides the NCO order once per plan: the dropped
+    // second-order term is e^2/2 with |e| <= 1.5 ulp(place); below 2^27 rad that is <= 2.5e-16, inside the
+    // scheme's ~4e-16 error budget, above it the second-order kernel is used
+    p->nco = !p->has_shift ? 0 : ((std::fabs(p->ratio) * (double)d.n_samples > 134217728.0) ? 2 : 1);
     if (const char *e = getenv("QD_NCO_ORDER")) { int v = atoi(e); if (p->has_shift && (v == 1 || v == 2)) p->nco = v; }
 
     // tile geometry: a shape-specialised kernel dictates G; otherwise pick G for LDS / lane use
@@ -896,7 +897,7 @@ int qd_shift(qd_c32 *buf, size_t n, uint64_t abs_off, double ratio, int mem) {
     HIPCHK(hipMalloc(&jt.p, ROW * sizeof(double2)));
     hipLaunchKernelGGL(k_rowtab, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, 0, ratio, ROW, r0, rows, static_cast<RowBase *>(rt.p));
     hipLaunchKernelGGL(k_jtab, dim3(2), dim3(256), 0, 0, ratio, ROW, static_cast<double2 *>(jt.p));
-    int so = (std::fabs(ratio) * (double)(abs_off + n) > 67108864.0) ? 1 : 0;
+    int so = (std::fabs(ratio) * (double)(abs_off + n) > 134217728.0) ? 1 : 0;
     uint32_t grid = (uint32_t)(rows < 4096 ? rows : 4096);
     hipLaunchKernelGGL(k_shift, dim3(grid), dim3(256), 0, 0, d, abs_off, (uint64_t)n, ratio, static_cast<const RowBase *>(rt.p), r0, rows,
                        static_cast<const double2 *>(jt.p), so);
