@@ -9,12 +9,16 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "quadrs_hip.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("qd_chain.h", "qd_device.h")] + [
+# (source, extra flags): qd_longfir.hip holds the FIR-dominated shape kernels, built without the SLP
+# vectorizer (scalar f32 accumulate chains instead of v_pk_*; see the file header)
+SRC = [(os.path.join(HERE, "csrc", "quadrs_hip.hip"), []),
+       (os.path.join(HERE, "csrc", "qd_longfir.hip"), ["-fno-slp-vectorize"])]
+DEPS = [s for s, _ in SRC] + [os.path.join(HERE, "csrc", f) for f in ("qd_chain.h", "qd_device.h", "qd_registry.h")] + [
     os.path.join(ROOT, "include", "quadrs_hip.h")]
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
 OUT = os.path.join(HERE, "libquadrs_hip.so")
 
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include")]
 
 
@@ -51,7 +55,19 @@ def build_cli(force=False, verbose=False):
 
 def build(force=False, verbose=False, extra=()):
     if force or needs_build():
-        cmd = [hipcc()] + FLAGS + list(extra) + ["-o", OUT] + SRC + ["-lhiprtc", "-ldl"]
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        objs, procs = [], []
+        for src, more in SRC:                      # the translation units compile in parallel
+            obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+            cmd = [hipcc()] + FLAGS + more + list(extra) + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lhiprtc", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -32,7 +32,7 @@ namespace qd {
 #define QD_STAMP_ROW(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_row[k] += t_ - st_prev; st_acc[0] += t_ - st_prev; st_prev = t_; } while (0)
 #define QD_STAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); } while (0)
 #define QD_STAMP_AT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 1) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[33 + k_], st_row[k_]); if (w_ == 0) atomicAdd(&P.stamps[32], (unsigned long long)st_tiles); } } while (0)
+#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 256) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 1) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[33 + k_], st_row[k_]); if (w_ == 0) atomicAdd(&P.stamps[32], (unsigned long long)st_tiles); } } while (0)
 #define QD_STAMP_TILE() do { ++st_tiles; } while (0)
 #else
 #define QD_STAMP_DECL
@@ -112,10 +112,19 @@ constexpr uint32_t ct_raw_elems(uint32_t W, uint32_t S, uint32_t D, uint32_t T, 
     return (elems + 1) & ~1u;
 }
 
-template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8>
+template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1>
 struct FixedGeo {
     static constexpr bool kFixed = true;
     static constexpr uint32_t kFirBlock = FIRB_;   // taps per software-pipelined FIR block (register budget knob)
+    // outputs per lane in the FIR (register tiling): each LDS sample read feeds FIRR_ accumulators.
+    // Needs 8-aligned geometry; falls back to 1 otherwise.
+    static constexpr uint32_t kFirTile = (FIRR_ > 1 && D_ % 8 == 0 && ((T_ - T_ / 2) % D_) % 8 == 0 && T_ % 8 == 0 && (T_ / 2) % 8 == 0 &&
+                                          W_ % FIRR_ == 0 && S_ % FIRR_ == 0 && ct_pow2(D_) && ct_pow2(FIRR_)) ? FIRR_ : 1;
+    // LDS pad period: one pad element per PD samples.  PD = D for the lane-per-output FIR (lane stride D + 1:
+    // odd, conflict-free ds_read_b64); the register-tiled FIR strides lanes by kFirTile rows, so it pads once
+    // per kFirTile * D samples to keep the lane stride odd.
+    static constexpr uint32_t PD = D_ * kFirTile;
+    static constexpr uint32_t pshift = ct_pow2(PD) ? ct_log2(PD) : 0xffffffffu;
     __device__ __forceinline__ explicit FixedGeo(const ChainParams &) {}
     static constexpr uint32_t W = W_, S = S_, D = D_, T = T_, G = G_;
     static constexpr uint32_t logW = ct_log2(W_);
@@ -137,9 +146,10 @@ struct FixedGeo {
 struct DynGeo {
     static constexpr bool kFixed = false;
     static constexpr bool kShared = false;
-    uint32_t W, S, D, T, G, logW, Dp, dshift, dmagic, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
+    static constexpr uint32_t kFirTile = 1;
+    uint32_t W, S, D, T, G, logW, Dp, dshift, dmagic, PD, pshift, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
     __device__ __forceinline__ explicit DynGeo(const ChainParams &P)
-        : W(P.W), S(P.S), D(P.D), T(P.T), G(P.G), logW(P.logW), Dp(P.Dp), dshift(P.dshift), dmagic(P.dmagic),
+        : W(P.W), S(P.S), D(P.D), T(P.T), G(P.G), logW(P.logW), Dp(P.Dp), dshift(P.dshift), dmagic(P.dmagic), PD(P.D), pshift(P.dshift),
           a0(P.a0), b0(P.b0), T_fast(P.T_fast), a1(P.a1), b1(P.b1), log_base(P.log_base), base_len(P.base_len),
           layers(P.layers), lds_raw_elems(P.lds_raw_elems) {}
 };
@@ -258,11 +268,11 @@ __device__ __forceinline__ RowBase load_rowbase(const ChainParams &P, uint64_t r
     return rb;
 }
 
-// tile-relative sample index m -> row-padded LDS element  m + (m / D) * (Dp - D)   (Dp - D is 0 or 1)
+// tile-relative sample index m -> padded LDS element  m + m / PD  (PD = D except for the register-tiled FIR; no pad for odd D)
 template <class GeoT>
 __device__ __forceinline__ uint32_t pad_index(const GeoT &geo, uint32_t m) {
     if (geo.Dp == geo.D) return m;
-    if (geo.dshift != 0xffffffffu) return m + (m >> geo.dshift);
+    if (geo.pshift != 0xffffffffu) return m + (m >> geo.pshift);
     return m + __umulhi(m, geo.dmagic);
 }
 
@@ -303,11 +313,11 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
             for (int u = 0; u < SPL; ++u) x[u] = cmul(x[u], m[u]);   // buf[i] *= mul (src/shift.rs:51)
         }
     }
-    // Additive addressing: rel is a multiple of D (n_start and ROW both are) and SPL divides D, so
+    // Additive addressing: rel is a multiple of PD (n_start and ROW both are) and SPL divides PD, so
     // pad(rel + t) = pad_s(rel) + pad(t) and a lane's SPL samples are contiguous in LDS.
-    const bool additive = geo.dshift != 0xffffffffu && geo.D >= (uint32_t)SPL && geo.D <= ROW;
+    const bool additive = geo.pshift != 0xffffffffu && geo.PD >= (uint32_t)SPL && geo.PD <= ROW;
     if (additive) {
-        const int32_t row_pad = rel + ((geo.Dp != geo.D) ? (rel >> geo.dshift) : 0);      // uniform, signed
+        const int32_t row_pad = rel + ((geo.Dp != geo.D) ? (rel >> geo.pshift) : 0);      // uniform, signed
         float2 *dst = raw + (row_pad + (int32_t)lane_pad);
 #pragma unroll
         for (int u = 0; u < SPL; ++u)
@@ -493,6 +503,122 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
     }
 }
 
+// Register-tiled FIR (shape-specialised kernels, long filters): one lane computes R consecutive
+// outputs q0..q0+R-1.  The lane walks the L = (R-1)*D + T samples its outputs touch ONCE (BS-sample
+// blocks, ping-ponged registers); sample i feeds accumulator r with tap i - r*D.  Every accumulator
+// still sees its products in ascending-j order with separately rounded multiply and add, so the
+// results are bit-identical to the one-output-per-lane form, but LDS sample traffic drops R-fold
+// (the one-output form reads 8 B of LDS per MAC and is LDS-bandwidth-bound for T/D >> 1).
+// Truncated outputs (jmax[r] < T) are accumulator snapshots, as in fir_span.
+// BS = 4 keeps the two register sets (samples + R tap vectors each) at 16 + 8R VGPRs: the phase-1
+// prefetch registers stay live across the FIR, so the budget here is ~90 of the 128.
+template <int R, class GeoT, int BS = 4>
+__device__ __forceinline__ void fir_tiled(const float2 *lanep, const uint32_t *jmax, const float *h, float2 *full, float2 *snap) {
+    constexpr uint32_t D = GeoT::D, T = GeoT::T, c = GeoT::c;
+    constexpr uint32_t L = (R - 1) * D + T, NB = L / BS;
+    static_assert(GeoT::PD == R * D && GeoT::pshift != 0xffffffffu, "pad period of the register-tiled layout");
+    static_assert(BS == 4 || BS == 8, "block of 4 or 8 samples");
+    static_assert(L % 8 == 0 && D % 8 == 0 && c % 8 == 0, "register-tiled FIR needs 8-aligned geometry");
+    float ar[R], ai[R], sr[R], si[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ar[r] = 0.f; ai[r] = 0.f; sr[r] = 0.f; si[r] = 0.f; }
+    auto load_x = [&](uint32_t blk, float2 *x) {
+        // lanep is the padded LDS address of sample q0*D (a multiple of the pad period), so pad(q0*D + t) =
+        // pad(q0*D) + pad(t) with a wave-uniform second term; a block never straddles a pad
+        const uint32_t t = c + blk * BS;
+        const float2 *pp = lanep + (t + (t >> GeoT::pshift));
+        const uint64_t *p8 = reinterpret_cast<const uint64_t *>(pp);  // one 8-byte LDS read per sample (rows are 8-byte aligned only)
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            const uint64_t v = p8[i];
+            x[i] = make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+        }
+    };
+    auto load_h1 = [&](uint32_t j0, float *hh) {                   // BS taps from h + j0 (16-byte aligned broadcast reads)
+        const float4 *hp = reinterpret_cast<const float4 *>(h + j0);
+#pragma unroll
+        for (int v = 0; v < BS / 4; ++v) {
+            const float4 q = hp[v];
+            hh[4 * v + 0] = q.x; hh[4 * v + 1] = q.y; hh[4 * v + 2] = q.z; hh[4 * v + 3] = q.w;
+        }
+    };
+    auto load_h = [&](uint32_t blk, float (*hh)[BS]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) load_h1(blk * BS - r * D, hh[r]);
+    };
+    // only a wave that owns truncated outputs pays for the snapshot compares
+    bool lane_trunc = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) lane_trunc |= jmax[r] < T;
+    const bool need_snap = __builtin_amdgcn_ballot_w64(lane_trunc) != 0;
+    auto snap_check = [&](int r, uint32_t j0) {                     // j0 wave-uniform
+        if (need_snap && j0 >= T / 2 + D && ((j0 - T / 2) % D) == 0) {
+            if (jmax[r] == j0) { sr[r] = ar[r]; si[r] = ai[r]; }
+        }
+    };
+    // interior block (every accumulator active): the R chains are interleaved tap by tap so that
+    // consecutive VALU ops are independent; its taps were fetched one block ahead with the samples
+    auto mac_int = [&](uint32_t blk, const float2 *x, const float (*hh)[BS]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) snap_check(r, blk * BS - r * D);
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                ar[r] = ar[r] + x[i].x * hh[r][i];
+                ai[r] = ai[r] + x[i].y * hh[r][i];
+            }
+        }
+    };
+    // edge block (compile-time blk): only the accumulators whose tap range covers it take part
+    auto mac_edge = [&](uint32_t blk, const float2 *x) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int32_t j0 = (int32_t)(blk * BS) - r * (int32_t)D;
+            if (j0 >= 0 && j0 < (int32_t)T) {
+                snap_check(r, (uint32_t)j0);
+                float hh[BS];
+                load_h1((uint32_t)j0, hh);
+#pragma unroll
+                for (int i = 0; i < BS; ++i) {
+                    ar[r] = ar[r] + x[i].x * hh[i];
+                    ai[r] = ai[r] + x[i].y * hh[i];
+                }
+            }
+        }
+    };
+    constexpr uint32_t P = (R - 1) * D / BS, E = T / BS;        // interior blocks are [P, E)
+    static_assert(E > P + 2, "filter too short for the register-tiled FIR");
+    constexpr uint32_t P2 = P + ((E - P) & 1);                  // even interior trip count
+    float2 xa[BS], xb[BS];
+    float ha[R][BS], hb[R][BS];
+#pragma unroll
+    for (uint32_t blk = 0; blk < P2; ++blk) {
+        load_x(blk, xa);
+        if (blk < P) mac_edge(blk, xa); else { load_h(blk, ha); mac_int(blk, xa, ha); }
+    }
+    load_x(P2, xa); load_h(P2, ha);
+    for (uint32_t blk = P2; blk + 2 < E; blk += 2) {              // branch-free body: two register sets, no copies
+        load_x(blk + 1, xb); load_h(blk + 1, hb);
+        mac_int(blk, xa, ha);
+        __builtin_amdgcn_sched_barrier(0);     // keep set A's reload below its last use: no register copies at the back edge
+        load_x(blk + 2, xa); load_h(blk + 2, ha);
+        mac_int(blk + 1, xb, hb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load_x(E - 1, xb); load_h(E - 1, hb);                         // last interior pair, peeled
+    mac_int(E - 2, xa, ha);
+    load_x(E, xa);                                                // the first edge block (always inside the tile)
+    mac_int(E - 1, xb, hb);
+#pragma unroll
+    for (uint32_t blk = E; blk < NB; ++blk) {
+        if (blk > E) load_x(blk, xa);
+        mac_edge(blk, xa);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { full[r] = make_float2(ar[r], ai[r]); snap[r] = make_float2(sr[r], si[r]); }
+}
+
 // ---------------------------------------------------------------- the kernel
 // RCH / WHOLE: prefetch geometry.
 //   WHOLE (rows per tile <= RCH): slot i holds row i of the workgroup's *next* tile; it is refilled
@@ -524,18 +650,23 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     if constexpr (FMT == 1) { if (tid < 256) lut[tid] = unpack_cs8(tid); }
     if constexpr (FMT == 2) { if (tid < 256) lut[tid] = unpack_cu8(tid); }
 
+    // Per-lane NCO constants: 4 doubles per sample slot.  Kernels whose FIR is register-hungry (register-tiled
+    // long filters) re-derive them at the top of every tile instead of keeping 8*SPL VGPRs live across the FIR
+    // (the table is L2-resident; a tile of such a shape costs tens of thousands of cycles).
+    constexpr bool kReloadLane = HAS_SHIFT && GeoT::kFixed && GeoT::kFirTile > 1;
     LaneRot lr[SPL];
-    if constexpr (HAS_SHIFT) {
+    auto load_lane_rot = [&](uint32_t first) {
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
-            uint32_t j = tid * SPL + u;
+            uint32_t j = first + u;
             double2 cs = P.jtab[j];
             lr[u].jf = (double)j;
             lr[u].tj = lr[u].jf * P.ratio;
             lr[u].c = cs.x;
             lr[u].s = cs.y;
         }
-    }
+    };
+    if constexpr (HAS_SHIFT && !kReloadLane) load_lane_rot(tid * SPL);
     const uint32_t lane_pad = pad_index(geo, tid * SPL);      // LDS element of this lane's first sample in a row
     // Stage the layer twiddles in LDS: phases 2-4 then issue no vector-memory loads, so nothing in
     // them has to wait behind the next tile's prefetch (vmcnt retires in order).
@@ -570,6 +701,11 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
         // ---------------- phase 1: HBM -> unpack -> NCO -> LDS
         double rt_pf = 0.0;
+        if constexpr (kReloadLane) {
+            uint32_t first = tid * SPL;
+            asm volatile("" : "+v"(first));          // opaque per tile: the loads are not hoisted out of the tile loop
+            load_lane_rot(first);
+        }
         if constexpr (WHOLE) {
             TileGeo ng = tile_geo<FMT, NT>(P, geo, tile + gridDim.x, n_tiles);
             if (!ng.valid) ng = tg;                  // last tile of this workgroup: harmless re-loads
@@ -644,6 +780,27 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         if constexpr (GeoT::kFixed) shared = GeoT::kShared; else shared = HAS_FIR && S < W && ntrunc <= S && !(P.dbg & 2) && P.epi != 3;
         if constexpr (!GeoT::kFixed || GeoT::kShared) if (shared) {
             const uint32_t Q = (g_cnt - 1) * S + W;
+            if constexpr (GeoT::kFixed && GeoT::kFirTile > 1) {
+                constexpr int R = (int)GeoT::kFirTile;
+                for (uint32_t q0 = tid * R; q0 < Q; q0 += NT * R) {
+                    uint32_t jm[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t qi = q0 + r;
+                        jm[r] = T;
+                        if (qi + ntrunc >= W) {
+                            const uint32_t g = (qi - (W - ntrunc)) / S, k = qi - g * S;
+                            if (k < W && g < g_cnt) { const uint32_t j2 = (W - k) * D + T / 2; if (j2 < T) jm[r] = j2; }
+                        }
+                    }
+                    float2 full[R], snp[R];
+                    fir_tiled<R, GeoT>(raw + (q0 * D + q0 / R), jm, tapl, full, snp);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (q0 + r < Q) { dec[q0 + r] = full[r]; if (jm[r] < T) trc[q0 + r] = snp[r]; }
+                    }
+                }
+            } else
             for (uint32_t qi = tid; qi < Q; qi += NT) {
                 uint32_t jmax = T;
                 if (qi + ntrunc >= W) {                      // may be in the truncated tail of window g
@@ -676,6 +833,23 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
             }
         }
+        if constexpr (GeoT::kFixed && !GeoT::kShared && GeoT::kFirTile > 1 && HAS_FIR) {
+            constexpr int R = (int)GeoT::kFirTile;
+            for (uint32_t o0 = tid * R; o0 < n_out; o0 += NT * R) {
+                const uint32_t g = o0 >> logW, k0 = o0 & (W - 1);          // W % R == 0: the R outputs share a window
+                uint32_t jm[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const uint32_t j2 = (W - (k0 + r)) * D + T / 2; jm[r] = j2 < T ? j2 : T; }
+                float2 full[R], snp[R];
+                { const uint32_t q0 = g * S + k0; fir_tiled<R, GeoT>(raw + (q0 * D + q0 / R), jm, tapl, full, snp); }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t k = k0 + r;
+                    const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                    fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = jm[r] < T ? snp[r] : full[r];
+                }
+            }
+        } else
         if constexpr (!GeoT::kFixed || !GeoT::kShared) if (!shared)
         for (uint32_t o = tid; o < n_out; o += NT) {
             const uint32_t g = o >> logW, k = o & (W - 1);

@@ -1,0 +1,28 @@
+// qd_registry.h — table entries of the shape-specialised (FixedGeo) chain kernels.
+// Two translation units contribute entries: quadrs_hip.hip (default flags) and qd_longfir.hip
+// (FIR-dominated shapes, compiled with -fno-slp-vectorize, see there).
+#pragma once
+#include "qd_chain.h"
+
+namespace qd {
+
+typedef void (*chain_fn)(const ChainParams);
+
+struct FixedEntry {
+    int fmt, nco;
+    uint32_t W, S, D, T, G;
+    int lb;              // register budget the build targets: waves per SIMD (4 -> 128 VGPRs, 2 -> 256)
+    int nt;              // workgroup size
+    chain_fn fn;
+    const char *name;
+};
+
+#define QD_FIXED(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NAME) \
+    { F, NCO, W, S, D, T, G, LB, qd::kThreads, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
+#define QD_FIXED_NT(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, FIRR, NAME) \
+    { F, NCO, W, S, D, T, G, LB, NT, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, FIRB, FIRR>, true, RCH, WHOLE, true, LB, NT>, NAME }
+
+// defined in qd_longfir.hip
+const FixedEntry *longfir_entries(int *count);
+
+}  // namespace qd

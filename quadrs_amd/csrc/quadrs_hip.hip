@@ -21,6 +21,7 @@
 
 #include "../../include/quadrs_hip.h"
 #include "qd_chain.h"
+#include "qd_registry.h"
 
 using namespace qd;
 
@@ -199,7 +200,6 @@ FftLayout fft_layout(uint64_t W) {
     return L;
 }
 
-typedef void (*chain_fn)(const ChainParams);
 
 #ifdef QD_DEV_FAST   // development builds: cf32 only, to keep hipcc turnaround short
 #define QD_FMT_CASES(X) case 0: return X(0);
@@ -231,18 +231,6 @@ chain_fn pick_generic(int fmt, int nco, bool fir, bool aligned) {
 
 // ---- shape-specialised kernels (FixedGeo): the chain shapes of BASELINE.json / the README.
 // Same source as the generic kernel with W,S,D,T,G as compile-time constants.
-struct FixedEntry {
-    int fmt, nco;
-    uint32_t W, S, D, T, G;
-    int wg_per_cu;       // register budget the build targets (waves per SIMD)
-    int nt;              // workgroup size
-    chain_fn fn;
-    const char *name;
-};
-#define QD_FIXED(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NAME) \
-    { F, NCO, W, S, D, T, G, LB, kThreads, k_chain<F, NCO, FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
-#define QD_FIXED_NT(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, NAME) \
-    { F, NCO, W, S, D, T, G, LB, NT, k_chain<F, NCO, FixedGeo<W, S, D, T, G, FIRB>, true, RCH, WHOLE, true, LB, NT>, NAME }
 const FixedEntry kFixed[] = {
     // configs[1]  "shift 280000 | lowpass -power 20 -decimate 16 2000000 | sparkfft -width 128"   (README.md:57-63)
     QD_FIXED(0, 1, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
@@ -250,22 +238,20 @@ const FixedEntry kFixed[] = {
     // north_star target sentence: 200-tap FIR decimate 32 -> 128-pt FFT
     QD_FIXED(0, 1, 128, 128, 32, 200, 1, 9, true, 4, "cfg3p"),
     QD_FIXED(0, 2, 128, 128, 32, 200, 1, 9, true, 4, "cfg3p"),
-    // README.md:90-94 / configs[2]  "lowpass -power 200 -decimate 32 200000 | sparkfft -width 64 -stride 16"
-    QD_FIXED(0, 1, 64, 16, 32, 400, 4, 9, true, 4, "fsk5"),
-    QD_FIXED(0, 2, 64, 16, 32, 400, 4, 9, true, 4, "fsk5"),
-#ifndef QD_DEV_FAST
-    QD_FIXED(1, 1, 64, 16, 32, 400, 4, 5, true, 4, "cfg3"),
-    QD_FIXED(1, 2, 64, 16, 32, 400, 4, 5, true, 4, "cfg3"),
-#endif
+    // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
-    QD_FIXED_NT(0, 0, 1024, 1024, 8, 512, 1, 5, true, 4, 1024, 4, "cfg4"),
+    QD_FIXED_NT(0, 0, 1024, 1024, 8, 512, 1, 5, true, 4, 1024, 4, 2, "cfg4"),
 };
 
 const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t D, uint32_t T) {
     if (getenv("QD_NO_FIXED")) return nullptr;       // tests compare the specialised and generic kernels
     for (const FixedEntry &e : kFixed)
         if (e.fmt == fmt && e.nco == nco && e.W == W && e.S == S && e.D == D && e.T == T) return &e;
+    int n_long = 0;
+    const FixedEntry *lf = longfir_entries(&n_long);
+    for (int i = 0; i < n_long; ++i)
+        if (lf[i].fmt == fmt && lf[i].nco == nco && lf[i].W == W && lf[i].S == S && lf[i].D == D && lf[i].T == T) return &lf[i];
     return nullptr;
 }
 
@@ -274,9 +260,10 @@ const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t 
 // process.  QD_JIT=0 disables, QD_JIT=1 forces it for every plan; by default only streams whose chain
 // input is >= 16 MiB pay the ~0.3 s compile.
 struct JitKey {
-    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G;
+    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1;
     bool operator<(const JitKey &o) const {
-        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G) < std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G);
+        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr) <
+               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr);
     }
 };
 std::mutex g_jit_mu;
@@ -300,15 +287,21 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
     if (!probe) { *why = "kernel headers not found next to the library (" + dir + ")"; return nullptr; }
     fclose(probe);
     char name[512];
-    snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
-             k.S, k.D, k.T, k.G, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
+    snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
+             k.S, k.D, k.T, k.G, k.firb, k.firr, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
     std::string src = std::string("#include \"qd_chain.h\"\ntemplate __global__ void ") + name + "(const qd::ChainParams);\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "qd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *why = "hiprtcCreateProgram failed"; return nullptr; }
     hiprtcAddNameExpression(prog, name);
     const std::string inc = "-I" + dir;
+#ifdef QD_STAMP
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str(), "-DQD_STAMP"};
+#else
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str()};
-    hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
+#endif
+    std::vector<const char *> optv(opts, opts + sizeof opts / sizeof opts[0]);
+    if (getenv("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");      // development: scalar f32 instead of v_pk_* in the FIR chains
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)optv.size(), optv.data());
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
         std::string log(ls, 0); if (ls) hiprtcGetProgramLog(prog, &log[0]);
@@ -497,7 +490,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
             void *args[] = {&P};
-            HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, kThreads, 1, 1, (unsigned)p->geo.lds_bytes, st, args, nullptr));
+            HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->nt, 1, 1, (unsigned)p->geo.lds_bytes, st, args, nullptr));
         } else {
             hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->nt : kThreads), p->geo.lds_bytes, st, P);
             HIPCHK(hipGetLastError());
@@ -612,7 +605,22 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
                     (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
     p->fixed = (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS) ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
-    if (p->fixed) {
+    // QD_TUNE=G:NT:FIRR:FIRB:LB (development): force a plan-time build with this tiling instead of the table / heuristics
+    // (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256)
+    uint32_t tune[5] = {0, 0, 1, 8, 4};
+    bool tuned = false;
+    if (const char *e = getenv("QD_TUNE")) {
+        if (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && sscanf(e, "%u:%u:%u:%u:%u", &tune[0], &tune[1], &tune[2], &tune[3], &tune[4]) >= 2 && tune[4] >= 1 && tune[4] <= 8 &&
+            tune[0] >= 1 && (tune[1] == 256 || tune[1] == 512 || tune[1] == 1024) &&
+            lds_for(tune[0], p->W, p->S, p->D, T_lds, nullptr) <= kLdsMax) {
+            tuned = true;
+            p->fixed = nullptr;
+        }
+    }
+    if (tuned) {
+        G = tune[0];
+        p->nt = (int)tune[1];
+    } else if (p->fixed) {
         G = p->fixed->G;
         p->nt = p->fixed->nt;
     } else {
@@ -634,24 +642,26 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const char *jenv = getenv("QD_JIT");
         const int jmode = jenv ? atoi(jenv) : -1;                       // -1 auto, 0 off, 1 force
         const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
-        const bool want = !p->fixed && !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS &&
-                          (jmode == 1 || (jmode != 0 && in_bytes >= (16ull << 20)));
+        const bool want = tuned || (!p->fixed && !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS &&
+                                    (jmode == 1 || (jmode != 0 && in_bytes >= (16ull << 20))));
         if (want) {
-            const uint64_t ROW = (uint64_t)kThreads * spl_of(d.format);
+            const uint64_t ROW = (uint64_t)p->nt * spl_of(d.format);
             const uint64_t tile_raw = (uint64_t)(G - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
             // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
             const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
-            JitKey k{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, 4, kThreads,
-                     p->W, p->S, p->D, p->T, G};
+            JitKey k{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, (int)tune[4], p->nt,
+                     p->W, p->S, p->D, p->T, G, tune[3], tune[2]};
             p->jit_fn = jit_chain_kernel(k, &p->jit_note);
+            if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "QD_TUNE build failed: %s", p->jit_note.c_str());
         }
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->n_cu = prop.multiProcessorCount;
     int by_lds = (int)(kLdsMax / p->geo.lds_bytes);
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
-    if (p->fixed && p->wg_per_cu > p->fixed->wg_per_cu) p->wg_per_cu = p->fixed->wg_per_cu;
+    if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->nt > kThreads) { int by_threads = 2048 / p->nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
+    if (tuned) { int by_regs = (int)(tune[4] * 4 * 64) / p->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->jit_fn && p->geo.lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->geo.lds_bytes) != hipSuccess)
             p->jit_fn = nullptr;     // fall back to the generic kernel
