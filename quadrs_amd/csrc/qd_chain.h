@@ -379,8 +379,8 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                     acci = acci + x.y * hh;
                 }
             }
-        } else if (n > 256 && GeoT::kFirBlock >= 8 && D % 8 == 0 && b % 8 == 0 && n % 8 == 0 && (!SNAP || (geo.T % D) % 8 == 0) && !PRED) {
-            // very long filters: ROLLED and software-pipelined.  8-tap blocks never straddle an LDS row
+        } else if (n >= 128 && GeoT::kFirBlock >= 8 && D % 8 == 0 && b % 8 == 0 && n % 8 == 0 && (!SNAP || (geo.T % D) % 8 == 0) && !PRED) {
+            // long filters on 8-aligned geometry: ROLLED and software-pipelined.  8-tap blocks never straddle an LDS row
             // (D, b multiples of 8); two register sets ping-pong so that block k+1's LDS reads (8 samples
             // + two broadcast ds_read_b128 of taps) are in flight while block k is accumulated; a lane's
             // jmax (multiple of 8 here) can only be hit at a block boundary, so the snapshot is one

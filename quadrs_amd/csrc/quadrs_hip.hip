@@ -260,10 +260,10 @@ const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t 
 // process.  QD_JIT=0 disables, QD_JIT=1 forces it for every plan; by default only streams whose chain
 // input is >= 16 MiB pay the ~0.3 s compile.
 struct JitKey {
-    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1;
+    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1; int noslp = 0;
     bool operator<(const JitKey &o) const {
-        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr) <
-               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr);
+        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr, noslp) <
+               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr, o.noslp);
     }
 };
 std::mutex g_jit_mu;
@@ -300,7 +300,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str()};
 #endif
     std::vector<const char *> optv(opts, opts + sizeof opts / sizeof opts[0]);
-    if (getenv("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");      // development: scalar f32 instead of v_pk_* in the FIR chains
+    if (k.noslp || getenv("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");   // scalar f32 accumulate chains (see qd_longfir.hip)
     hiprtcResult r = hiprtcCompileProgram(prog, (int)optv.size(), optv.data());
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
@@ -371,6 +371,11 @@ struct qd_plan {
     double2 *jtab_d = nullptr;
     RowBase *rowtab_d = nullptr;
     uint64_t rowtab_row0 = 0, rowtab_rows = 0;
+    // plans whose main kernel uses another workgroup size keep a second pair of NCO tables laid out for the
+    // 256-thread per-sample kernel that takes the windows at an unaligned slab end
+    double2 *jtab256_d = nullptr;
+    RowBase *rowtab256_d = nullptr;
+    uint64_t rowtab256_row0 = 0, rowtab256_rows = 0;
     // take_fft mode (generic kernels): per-window start offsets and an f32 window, both on the device
     const uint64_t *row_offsets_d = nullptr;
     const float *window_d = nullptr;
@@ -396,19 +401,23 @@ uint64_t out_bytes_per_window(const qd_plan *p) {
     }
 }
 
-int ensure_rowtab(qd_plan *p, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
-    if (!p->has_shift) return QD_OK;
-    const uint32_t ROW = p->nt * spl_of(p->d.format);
+int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowBase **tab, uint64_t *row0, uint64_t *nrows, uint64_t n_lo, uint64_t n_hi,
+                      hipStream_t st) {
     uint64_t r_lo = n_lo / ROW, r_hi = (n_hi + ROW - 1) / ROW + 1;
-    if (p->rowtab_d && r_lo >= p->rowtab_row0 && r_hi <= p->rowtab_row0 + p->rowtab_rows) return QD_OK;
-    if (p->rowtab_d) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(p->rowtab_d)); p->rowtab_d = nullptr; }
+    if (*tab && r_lo >= *row0 && r_hi <= *row0 + *nrows) return QD_OK;
+    if (*tab) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(*tab)); *tab = nullptr; }
     uint64_t rows = r_hi - r_lo;
-    HIPCHK(hipMalloc(&p->rowtab_d, rows * sizeof(RowBase)));
-    p->rowtab_row0 = r_lo; p->rowtab_rows = rows;
+    HIPCHK(hipMalloc(tab, rows * sizeof(RowBase)));
+    *row0 = r_lo; *nrows = rows;
     uint32_t blocks = (uint32_t)((rows + 255) / 256);
-    hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, p->rowtab_d);
+    hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, *tab);
     HIPCHK(hipGetLastError());
     return QD_OK;
+}
+
+int ensure_rowtab(qd_plan *p, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
+    if (!p->has_shift) return QD_OK;
+    return ensure_rowtab_for(p, p->nt * spl_of(p->d.format), &p->rowtab_d, &p->rowtab_row0, &p->rowtab_rows, n_lo, n_hi, st);
 }
 
 int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src_count, uint64_t first_window,
@@ -473,8 +482,12 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         n_aligned = n_windows;
         while (n_aligned > 0 && (first_window + n_aligned - 1) * step + rpw > usable) --n_aligned;
     }
-    if (n_aligned < n_windows && p->nt != kThreads && p->has_shift)
-        return fail(QD_ERR_UNSUPPORTED, "unaligned slab with a %d-thread shifted plan: NCO tables are laid out for that row length", p->nt);
+    const bool tail_tables = n_aligned < n_windows && p->nt != kThreads && p->has_shift;
+    if (tail_tables) {
+        const uint64_t t0 = (first_window + n_aligned) * p->S * p->D;
+        rc = ensure_rowtab_for(p, kThreads * spl, &p->rowtab256_d, &p->rowtab256_row0, &p->rowtab256_rows, t0, need1, st);
+        if (rc) return rc;
+    }
     uint64_t cap = (uint64_t)p->n_cu * p->wg_per_cu;
     if (const char *e = getenv("QD_WG_PER_CU")) cap = (uint64_t)p->n_cu * (uint64_t)atoi(e);   // tuning knob
     if (p->timing) {
@@ -486,6 +499,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         const uint64_t w_count = part == 0 ? n_aligned : n_windows - n_aligned;
         if (w_count == 0) continue;
         P.first_window = w_begin; P.n_windows = w_count;
+        if (part == 1 && tail_tables) { P.rowtab = p->rowtab256_d; P.rowtab_row0 = p->rowtab256_row0; P.jtab = p->jtab256_d; }
         const uint64_t n_tiles = (w_count + P.G - 1) / P.G;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
@@ -617,9 +631,28 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             p->fixed = nullptr;
         }
     }
-    if (tuned) {
+    // Plan-time specialisation is wanted for shapes without a built-in kernel once the stream is big enough to
+    // repay the ~0.3 s compile (QD_JIT=0 off, =1 always).
+    const char *jenv = getenv("QD_JIT");
+    const int jmode = jenv ? atoi(jenv) : -1;                       // -1 auto, 0 off, 1 force
+    const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
+    const bool jit_ok = !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS &&
+                        (jmode == 1 || (jmode != 0 && in_bytes >= (16ull << 20)));
+    // FIR-dominated shapes (>= 8 taps per input sample): a tile's FIR phase is latency-bound — one wave walks
+    // all T taps however few outputs the tile has — so take the largest tile with <= 512 FIR outputs that LDS
+    // allows, 512 threads, a 256-VGPR budget and scalar accumulate chains (measured 1.3-2.9x over the small-tile
+    // default on six such shapes, scripts/policy_probe.py)
+    const bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D;
+    int jit_lb = 4, jit_noslp = 0;
+    if (heavy) {
+        auto outs = [&](uint32_t g) { return p->S < p->W ? (uint64_t)(g - 1) * p->S + p->W : (uint64_t)g * p->W; };
+        while (G < 64 && outs(G + 1) <= 512 && lds_for(G + 1, p->W, p->S, p->D, T_lds, nullptr) <= kLdsMax) ++G;
+        if (p->n_windows && G > p->n_windows) G = (uint32_t)p->n_windows;
+        p->nt = 512; jit_lb = 2; jit_noslp = 1;
+    } else if (tuned) {
         G = tune[0];
         p->nt = (int)tune[1];
+        jit_lb = (int)tune[4];
     } else if (p->fixed) {
         G = p->fixed->G;
         p->nt = p->fixed->nt;
@@ -639,18 +672,14 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (!p->fn || !p->fn_unaligned) return fail(QD_ERR_UNSUPPORTED, "no kernel built for this format (QD_DEV_FAST build?)");
     {
         // plan-time specialisation for shapes without a built-in FixedGeo kernel
-        const char *jenv = getenv("QD_JIT");
-        const int jmode = jenv ? atoi(jenv) : -1;                       // -1 auto, 0 off, 1 force
-        const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
-        const bool want = tuned || (!p->fixed && !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS &&
-                                    (jmode == 1 || (jmode != 0 && in_bytes >= (16ull << 20))));
+        const bool want = tuned || (!p->fixed && jit_ok);
         if (want) {
             const uint64_t ROW = (uint64_t)p->nt * spl_of(d.format);
             const uint64_t tile_raw = (uint64_t)(G - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
             // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
             const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
-            JitKey k{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, (int)tune[4], p->nt,
-                     p->W, p->S, p->D, p->T, G, tune[3], tune[2]};
+            JitKey k{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, jit_lb, p->nt,
+                     p->W, p->S, p->D, p->T, G, tune[3], tune[2], jit_noslp};
             p->jit_fn = jit_chain_kernel(k, &p->jit_note);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "QD_TUNE build failed: %s", p->jit_note.c_str());
         }
@@ -661,11 +690,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->nt > kThreads) { int by_threads = 2048 / p->nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
-    if (tuned) { int by_regs = (int)(tune[4] * 4 * 64) / p->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
+    if (tuned || heavy) { int by_regs = (jit_lb * 4 * 64) / p->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->jit_fn && p->geo.lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->geo.lds_bytes) != hipSuccess)
             p->jit_fn = nullptr;     // fall back to the generic kernel
     }
+    if (heavy && !p->jit_fn) p->nt = kThreads;
     for (chain_fn f : {p->fn, p->fn_unaligned}) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)p->geo.lds_bytes);
@@ -690,6 +720,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         HIPCHK(hipMalloc(&p->jtab_d, ROW * sizeof(double2)));
         hipLaunchKernelGGL(k_jtab, dim3((ROW + 255) / 256), dim3(256), 0, 0, p->ratio, ROW, p->jtab_d);
         HIPCHK(hipGetLastError());
+        if (p->nt != kThreads) {
+            const uint32_t ROW256 = kThreads * spl_of(d.format);
+            HIPCHK(hipMalloc(&p->jtab256_d, ROW256 * sizeof(double2)));
+            hipLaunchKernelGGL(k_jtab, dim3((ROW256 + 255) / 256), dim3(256), 0, 0, p->ratio, ROW256, p->jtab256_d);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipDeviceSynchronize());
     }
     return QD_OK;
@@ -741,6 +777,8 @@ int qd_plan_destroy(qd_plan *p) {
     if (p->tw_d) (void)hipFree(p->tw_d);
     if (p->jtab_d) (void)hipFree(p->jtab_d);
     if (p->rowtab_d) (void)hipFree(p->rowtab_d);
+    if (p->jtab256_d) (void)hipFree(p->jtab256_d);
+    if (p->rowtab256_d) (void)hipFree(p->rowtab256_d);
     if (p->ev_made) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
     delete p;
     return QD_OK;

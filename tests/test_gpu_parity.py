@@ -355,6 +355,35 @@ def test_device_resident_run_equals_host_run(engine):
     assert torch.equal(out, out2)
 
 
+def test_unaligned_device_slab_under_a_wide_tile_plan(engine):
+    """The README FSK shape runs 512-thread tiles; windows at a slab whose first sample sits on an odd
+    (non-vector) boundary go through the 256-thread per-sample kernel, which needs NCO tables of its own
+    row length.  Device-resident, so nothing re-aligns the slab on the way."""
+    import torch
+    rng = np.random.default_rng(21)
+    N = 400_000
+    x = _signal(rng, N)
+    p = engine.Plan(0, 21_000_000, N, shift_hz=280000, lowpass=(200_000, 32, 400), width=64, stride=16)
+    if not os.environ.get("QD_NO_FIXED"):          # generic-only runs have 256-thread tiles everywhere
+        assert p.info.threads != 256
+    whole = p.run_host(x.tobytes())
+    src = torch.from_numpy(x).cuda()
+    first, count = p.src_range(11, 50)
+    assert (first - 1) % 2 == 1
+    slab = src[first - 1:first + count]
+    out = torch.empty(50, 64, device="cuda", dtype=torch.float32)
+    p.run_device(slab, out, 11, 50, src_first=first - 1, src_count=count + 1)
+    torch.cuda.synchronize()
+    assert bits_equal(out.cpu().numpy(), whole[11:61])
+    # slab ending mid-vector: the last windows take the per-sample kernel, the rest the tile kernel
+    first, count = p.src_range(0, 200)
+    slab = src[first:first + count + 1].contiguous()[:count]
+    out = torch.empty(200, 64, device="cuda", dtype=torch.float32)
+    p.run_device(slab, out, 0, 200, src_first=first, src_count=count)
+    torch.cuda.synchronize()
+    assert bits_equal(out.cpu().numpy(), whole[:200])
+
+
 @pytest.mark.parametrize("W,out_len,windowing,slice_", [(256, 32, 1, None), (64, 100, 0, (1000, 40_000)), (1024, 7, 1, (5, 60_000)),
                                                          (4, 2048, 1, None)])
 def test_take_fft_rows(engine, oracle, fsk, W, out_len, windowing, slice_):

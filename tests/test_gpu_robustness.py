@@ -138,7 +138,11 @@ def test_degenerate_sizes(engine, oracle):
 
 @pytest.mark.parametrize("fmt,lp,W,S,shift", [(0, (1_500_000, 12, 48), 256, 256, -1_250_000),     # D not a power of two
                                               (3, (300_000, 16, 100), 64, 32, 99_000),           # cs16, overlapping windows
-                                              (2, None, 32, 32, 5_000)])                         # cu8, no lowpass
+                                              (2, None, 32, 32, 5_000),                          # cu8, no lowpass
+                                              # FIR-dominated shapes (T >= 8 D): large 512-thread tiles, scalar accumulate chains
+                                              (1, (150_000, 64, 800), 32, 8, -40_000),
+                                              (0, (1_000_000, 8, 256), 128, 32, 310_000),
+                                              (0, (900_000, 16, 256), 512, 512, 77_000)])
 def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, fmt, lp, W, S, shift):
     """hiprtc: the same kernel source with the plan's geometry as compile-time constants must give
     the generic kernel's bits (and the oracle's)."""
@@ -150,6 +154,8 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
         monkeypatch.setenv("QD_JIT", mode)
         plans[mode] = engine.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=lp, width=W, stride=S)
     assert plans["0"].info.kernel_kind == 0 and plans["1"].info.kernel_kind == 2
+    if lp and lp[2] >= 8 * lp[1]:
+        assert plans["1"].info.threads == 512 and plans["1"].info.tile_windows >= plans["0"].info.tile_windows
     a, b = plans["0"].run_host(data), plans["1"].run_host(data)
     assert bits_equal(a, b)
     ch = oracle.Chain.from_bytes(data, fmt, 21_000_000).shift(shift)
