@@ -684,7 +684,20 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
     // Register prefetch pipeline.  Slots whose row does not exist in the tile re-load its last
     // row (an L2 hit) so that every load stays unconditional.
-    uint64_t tile = blockIdx.x;
+    // Tile walk.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2.
+    // Neighbouring tiles share their edge row (a tile is not a whole number of rows) and the FIR halo, so each
+    // XCD walks one contiguous eighth of the tile range: its workgroups sit on neighbouring tiles at the same
+    // time and the shared rows are L2 hits instead of a second HBM fetch.
+    uint64_t walk_base = 0, walk_local = blockIdx.x, walk_step = gridDim.x, walk_limit = n_tiles;
+    if ((gridDim.x & 7u) == 0 && n_tiles >= 8) {
+        const uint64_t n8 = (n_tiles + 7) / 8;
+        walk_base = (uint64_t)(blockIdx.x & 7u) * n8;
+        walk_local = blockIdx.x >> 3;
+        walk_step = gridDim.x >> 3;
+        walk_limit = walk_base >= n_tiles ? 0 : (n_tiles - walk_base < n8 ? n_tiles - walk_base : n8);
+    }
+    auto walk_tile = [&](uint64_t local) -> uint64_t { return local < walk_limit ? walk_base + local : n_tiles; };   // n_tiles = none
+    uint64_t tile = walk_tile(walk_local);
     TileGeo tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
     Vec pf[RCH];
     if (tg.valid) {
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             load_lane_rot(first);
         }
         if constexpr (WHOLE) {
-            TileGeo ng = tile_geo<FMT, NT>(P, geo, tile + gridDim.x, n_tiles);
+            TileGeo ng = tile_geo<FMT, NT>(P, geo, walk_tile(walk_local + walk_step), n_tiles);
             if (!ng.valid) ng = tg;                  // last tile of this workgroup: harmless re-loads
             rt_pf = prefetch_rowtab<HAS_SHIFT>(P, ng, tid);
             RowBase rb_next{};
@@ -742,7 +755,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 TileGeo ng = tg;
                 uint32_t rbase = r + RCH;
                 if (rbase >= tg.n_rows) {
-                    const TileGeo t2 = tile_geo<FMT, NT>(P, geo, tile + gridDim.x, n_tiles);
+                    const TileGeo t2 = tile_geo<FMT, NT>(P, geo, walk_tile(walk_local + walk_step), n_tiles);
                     if (t2.valid) { ng = t2; rbase = 0; rt_pf = prefetch_rowtab<HAS_SHIFT>(P, t2, tid); } else { rbase = tg.n_rows - 1; }
                 }
 #pragma unroll
@@ -977,7 +990,8 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         __syncthreads();
         QD_STAMP_AT(7);
         QD_STAMP_TILE();
-        tile += gridDim.x;
+        walk_local += walk_step;
+        tile = walk_tile(walk_local);
         tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
     }
     QD_STAMP_FLUSH();
