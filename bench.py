@@ -170,12 +170,14 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # K+1 HIP events chained through the timed region (event i closes launch i-1 and opens launch i): one marker
+    # between kernels instead of two keeps the GPU-side gap per step at ~2.5 us (scripts/launch_gap.py)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()          # same stream the ABI launches on (torch's current stream)
+    ev[0].record()              # same stream the ABI launches on (torch's current stream)
+    for i in range(args.steps):
         step()
-        b.record()
+        ev[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -185,7 +187,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))
 
     finite = bool(torch.isfinite(out).all().item())
     if rank == 0:
@@ -199,8 +201,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and args.samples_log2 is None:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                ent = tj.get("workloads", {}).get(args.workload)        # per-workload PMC result of the latest profile round
+                if ent and args.samples_log2 is None and world == 1:
+                    traffic = ent.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
