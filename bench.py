@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed launches before the warmup steps (clock ramp)")
     ap.add_argument("--samples-log2", type=int, default=None, help="override samples per GPU (2^k); rehearsals only")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0, halo staged through the host")
@@ -164,6 +165,12 @@ def main():
     def step():
         plan.run_device(slab, out, me.w0, nw, src_first=me.need_first, src_count=me.need_count)
 
+    # settle: the first launches of a process run at ramping clocks (a cfg2 step is ~0.27 ms, so W warmup steps
+    # alone can end before the GPU leaves its idle state); untimed, before the W warmup steps of the contract
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
