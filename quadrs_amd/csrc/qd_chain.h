@@ -141,12 +141,17 @@ struct FixedGeo {
     static constexpr uint32_t lds_raw_elems = ct_raw_elems(W_, S_, D_, T_, G_);
     static constexpr uint32_t kNtrunc = c ? (c + D_ - 1) / D_ - 1 : 0;
     static constexpr bool kShared = T_ > 0 && S_ < W_ && kNtrunc <= S_;     // shared-FIR mode (see phase 2)
+    // component-split FIR (fir_comp): mid-length filters whose tile leaves at least half the lanes without an output
+    static constexpr bool split_ok(uint32_t nt) {
+        return !kShared && kFirTile == 1 && D_ % 8 == 0 && T_ >= 64 && 2u * G_ * W_ <= nt;
+    }
 };
 
 struct DynGeo {
     static constexpr bool kFixed = false;
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
+    static constexpr bool split_ok(uint32_t) { return false; }
     uint32_t W, S, D, T, G, logW, Dp, dshift, dmagic, PD, pshift, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
     __device__ __forceinline__ explicit DynGeo(const ChainParams &P)
         : W(P.W), S(P.S), D(P.D), T(P.T), G(P.G), logW(P.logW), Dp(P.Dp), dshift(P.dshift), dmagic(P.dmagic), PD(P.D), pshift(P.dshift),
@@ -619,6 +624,75 @@ __device__ __forceinline__ void fir_tiled(const float2 *lanep, const uint32_t *j
     for (int r = 0; r < R; ++r) { full[r] = make_float2(ar[r], ai[r]); snap[r] = make_float2(sr[r], si[r]); }
 }
 
+// Component-split FIR (shape-specialised kernels whose tile has at most NT/2 outputs): a lane carries ONE of
+// the two independent accumulate chains of an output — acc.re += x.re*h or acc.im += x.im*h, exactly the
+// reference's two f32 chains (src/filter.rs:119) — so a tile with few outputs still fills the workgroup and
+// each lane reads 4 B of LDS per tap.  Same products, same order; only the lane that owns them changes.
+// xp points at this component of the first sample of the output's first LDS row.  8-tap blocks, two register
+// sets (block k+1's reads in flight while block k accumulates); a truncated output (jmax < T) is the
+// accumulator snapshot taken at tap jmax, as in fir_span.
+template <class GeoT>
+__device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const float *h) {
+    constexpr uint32_t D = GeoT::D, Dp = GeoT::Dp, T = GeoT::T, b = GeoT::b0;
+    // PRE taps reach the first 8-aligned LDS column; from there 8-tap blocks never straddle a row (D % 8 == 0),
+    // so the body is a ROLLED loop (fully unrolled, the scheduler hoists every read and spills ~150 VGPRs)
+    constexpr uint32_t PRE = (8 - b % 8) % 8, NBLK = (T - PRE) / 8, TAIL = (T - PRE) % 8;
+    constexpr uint32_t CPOS = (T / 2 + 8 * D - PRE) % 8;          // where in a block a possible jmax (T/2 + m*D) can sit
+    static_assert(D % 8 == 0 && NBLK >= 3, "component-split FIR geometry");
+    float acc = 0.f, snap = 0.f;
+    auto cand = [&](uint32_t jj) -> bool { return jj >= T / 2 + D && jj < T && ((jj - T / 2) % D) == 0; };
+    auto xoff = [&](uint32_t t) -> uint32_t { return 2 * ((t / D) * Dp + (t % D)); };
+#pragma unroll
+    for (uint32_t i = 0; i < PRE; ++i) {                                   // head (compile-time offsets)
+        if (cand(i)) { if (jmax == i) snap = acc; }
+        acc = acc + xp[xoff(b + i)] * h[i];
+    }
+    float xa[8], xb[8], ha[8], hb[8];
+    auto load = [&](uint32_t m, float *x, float *hh) {
+        const uint32_t t = b + PRE + 8 * m;                                // wave-uniform, multiple of 8
+        const float *pp = xp + xoff(t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = pp[2 * i];
+        if constexpr (PRE % 4 == 0) {
+            const float4 *hp = reinterpret_cast<const float4 *>(h + PRE + 8 * m);
+            const float4 h0 = hp[0], h1 = hp[1];
+            hh[0] = h0.x; hh[1] = h0.y; hh[2] = h0.z; hh[3] = h0.w; hh[4] = h1.x; hh[5] = h1.y; hh[6] = h1.z; hh[7] = h1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hh[i] = h[PRE + 8 * m + i];
+        }
+    };
+    auto mac = [&](uint32_t m, const float *x, const float *hh) {
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            if (i == CPOS) { const uint32_t jj = PRE + 8 * m + i; if (cand(jj) && jmax == jj) snap = acc; }
+            acc = acc + x[i] * hh[i];
+        }
+    };
+    constexpr uint32_t NPAIR = NBLK / 2;                                   // blocks [0, 2*NPAIR) in ping-pong pairs
+    load(0, xa, ha);
+    for (uint32_t m = 0; m + 2 < 2 * NPAIR; m += 2) {
+        load(m + 1, xb, hb);
+        mac(m, xa, ha);
+        __builtin_amdgcn_sched_barrier(0);      // set A is reloaded only below its last use: no copies at the back edge
+        load(m + 2, xa, ha);
+        mac(m + 1, xb, hb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load(2 * NPAIR - 1, xb, hb);
+    mac(2 * NPAIR - 2, xa, ha);
+    if constexpr (NBLK % 2) load(NBLK - 1, xa, ha);
+    mac(2 * NPAIR - 1, xb, hb);
+    if constexpr (NBLK % 2) mac(NBLK - 1, xa, ha);
+#pragma unroll
+    for (uint32_t i = 0; i < TAIL; ++i) {                                  // tail
+        const uint32_t jj = PRE + 8 * NBLK + i;
+        if (cand(jj)) { if (jmax == jj) snap = acc; }
+        acc = acc + xp[xoff(b + jj)] * h[jj];
+    }
+    return jmax < T ? snap : acc;
+}
+
 // ---------------------------------------------------------------- the kernel
 // RCH / WHOLE: prefetch geometry.
 //   WHOLE (rows per tile <= RCH): slot i holds row i of the workgroup's *next* tile; it is refilled
@@ -846,6 +920,19 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
             }
         }
+        constexpr bool kSplit = HAS_FIR && GeoT::split_ok((uint32_t)NT);
+        if constexpr (kSplit) {
+            for (uint32_t t = tid; t < 2u * n_out; t += NT) {
+                const uint32_t o = t >> 1, part = t & 1u;
+                const uint32_t g = o >> logW, k = o & (W - 1);
+                uint32_t jmax = (W - k) * D + T / 2;
+                if (jmax > T) jmax = T;
+                const float *xp = reinterpret_cast<const float *>(raw + (size_t)(g * S + k + geo.a0) * Dp) + part;
+                const float v = (P.dbg & 2) ? xp[0] : fir_comp<GeoT>(xp, jmax, tapl);     // dbg: timing-only ablation
+                const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                reinterpret_cast<float *>(fb + (g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base))[part] = v;
+            }
+        } else
         if constexpr (GeoT::kFixed && !GeoT::kShared && GeoT::kFirTile > 1 && HAS_FIR) {
             constexpr int R = (int)GeoT::kFirTile;
             for (uint32_t o0 = tid * R; o0 < n_out; o0 += NT * R) {
