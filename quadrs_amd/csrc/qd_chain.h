@@ -103,16 +103,16 @@ constexpr bool ct_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 constexpr uint32_t ct_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // LDS float2 elements the raw tile needs (same formula as the host's lds_for())
-constexpr uint32_t ct_raw_elems(uint32_t W, uint32_t S, uint32_t D, uint32_t T, uint32_t G) {
+constexpr uint32_t ct_raw_elems(uint32_t W, uint32_t S, uint32_t D, uint32_t T, uint32_t G, uint32_t pad_per_row = 1) {
     uint32_t tile_raw = (G - 1) * S * D + W * D + T;
-    uint32_t pad = (D % 2 == 0) ? tile_raw / D + 1 : 0;
+    uint32_t pad = (D % 2 == 0) ? pad_per_row * (tile_raw / D + 1) : 0;
     uint32_t elems = tile_raw + pad + 1;
     uint32_t min_elems = G * W / 2 + 1;
     if (elems < min_elems) elems = min_elems;
     return (elems + 1) & ~1u;
 }
 
-template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1>
+template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1>
 struct FixedGeo {
     static constexpr bool kFixed = true;
     static constexpr uint32_t kFirBlock = FIRB_;   // taps per software-pipelined FIR block (register budget knob)
@@ -128,7 +128,12 @@ struct FixedGeo {
     __device__ __forceinline__ explicit FixedGeo(const ChainParams &) {}
     static constexpr uint32_t W = W_, S = S_, D = D_, T = T_, G = G_;
     static constexpr uint32_t logW = ct_log2(W_);
-    static constexpr uint32_t Dp = D_ + ((D_ % 2 == 0) ? 1u : 0u);
+    // LDS pad elements per pad period.  1: odd lane stride, conflict-free single ds_read_b64 — but hipcc merges
+    // neighbouring reads into ds_read2_b64, which gfx950 serves at half the bytes per clock.  2 (even D, even
+    // first column): rows stay 16-byte aligned and the lane stride is 4*odd banks, so the FIR reads sample
+    // PAIRS with conflict-free ds_read_b128 at the full 256 B/clk (MI355X_MICROARCH.md, LDS table).
+    static constexpr uint32_t kPad = (D_ % 2 == 0) ? ((PAD_ == 2 && (T_ - T_ / 2) % 2 == 0) ? 2u : 1u) : 0u;
+    static constexpr uint32_t Dp = D_ + kPad;
     static constexpr uint32_t dshift = ct_pow2(D_) ? ct_log2(D_) : 0xffffffffu;
     static constexpr uint32_t dmagic = D_ > 1 ? (uint32_t)((1ull << 32) / D_ + 1) : 0u;
     static constexpr uint32_t c = T_ - T_ / 2;
@@ -138,12 +143,15 @@ struct FixedGeo {
     static constexpr uint32_t log_base = logW <= 3 ? logW : ((logW & 1) ? 3u : 4u);
     static constexpr uint32_t base_len = 1u << log_base;
     static constexpr uint32_t layers = (logW - log_base) / 2;
-    static constexpr uint32_t lds_raw_elems = ct_raw_elems(W_, S_, D_, T_, G_);
+    static constexpr uint32_t lds_raw_elems = ct_raw_elems(W_, S_, D_, T_, G_, kPad ? kPad : 1);
     static constexpr uint32_t kNtrunc = c ? (c + D_ - 1) / D_ - 1 : 0;
     static constexpr bool kShared = T_ > 0 && S_ < W_ && kNtrunc <= S_;     // shared-FIR mode (see phase 2)
     // component-split FIR (fir_comp): mid-length filters whose tile leaves at least half the lanes without an output
     static constexpr bool split_ok(uint32_t nt) {
-        return !kShared && kFirTile == 1 && D_ % 8 == 0 && T_ >= 64 && 2u * G_ * W_ <= nt;
+        return !kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * G_ * W_ <= nt;
+    }
+    static constexpr bool split_ok_shared(uint32_t nt) {      // same, shared-FIR mode: (G-1)*S + W outputs per tile
+        return kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * ((G_ - 1) * S_ + W_) <= nt;
     }
 };
 
@@ -152,9 +160,10 @@ struct DynGeo {
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
     static constexpr bool split_ok(uint32_t) { return false; }
-    uint32_t W, S, D, T, G, logW, Dp, dshift, dmagic, PD, pshift, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
+    static constexpr bool split_ok_shared(uint32_t) { return false; }
+    uint32_t W, S, D, T, G, logW, Dp, kPad, dshift, dmagic, PD, pshift, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
     __device__ __forceinline__ explicit DynGeo(const ChainParams &P)
-        : W(P.W), S(P.S), D(P.D), T(P.T), G(P.G), logW(P.logW), Dp(P.Dp), dshift(P.dshift), dmagic(P.dmagic), PD(P.D), pshift(P.dshift),
+        : W(P.W), S(P.S), D(P.D), T(P.T), G(P.G), logW(P.logW), Dp(P.Dp), kPad(P.Dp - P.D), dshift(P.dshift), dmagic(P.dmagic), PD(P.D), pshift(P.dshift),
           a0(P.a0), b0(P.b0), T_fast(P.T_fast), a1(P.a1), b1(P.b1), log_base(P.log_base), base_len(P.base_len),
           layers(P.layers), lds_raw_elems(P.lds_raw_elems) {}
 };
@@ -273,12 +282,12 @@ __device__ __forceinline__ RowBase load_rowbase(const ChainParams &P, uint64_t r
     return rb;
 }
 
-// tile-relative sample index m -> padded LDS element  m + m / PD  (PD = D except for the register-tiled FIR; no pad for odd D)
+// tile-relative sample index m -> padded LDS element  m + kPad * (m / PD)  (PD = D except for the register-tiled FIR; no pad for odd D)
 template <class GeoT>
 __device__ __forceinline__ uint32_t pad_index(const GeoT &geo, uint32_t m) {
     if (geo.Dp == geo.D) return m;
-    if (geo.pshift != 0xffffffffu) return m + (m >> geo.pshift);
-    return m + __umulhi(m, geo.dmagic);
+    if (geo.pshift != 0xffffffffu) return m + geo.kPad * (m >> geo.pshift);
+    return m + geo.kPad * __umulhi(m, geo.dmagic);
 }
 
 // unpack -> NCO -> park in LDS for one fetched row.
@@ -322,7 +331,7 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
     // pad(rel + t) = pad_s(rel) + pad(t) and a lane's SPL samples are contiguous in LDS.
     const bool additive = geo.pshift != 0xffffffffu && geo.PD >= (uint32_t)SPL && geo.PD <= ROW;
     if (additive) {
-        const int32_t row_pad = rel + ((geo.Dp != geo.D) ? (rel >> geo.pshift) : 0);      // uniform, signed
+        const int32_t row_pad = rel + ((geo.Dp != geo.D) ? (int32_t)geo.kPad * (rel >> geo.pshift) : 0);      // uniform, signed
         float2 *dst = raw + (row_pad + (int32_t)lane_pad);
 #pragma unroll
         for (int u = 0; u < SPL; ++u)
@@ -396,6 +405,11 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
             auto load_blk = [&](uint32_t blk, float2 *x, float4 *hh) {
                 const uint32_t t = b + blk * 8;
                 const float2 *pp = rowp + (t / D) * Dp + (t % D);          // wave-uniform offset
+                if constexpr (GeoT::kPad == 2) {                           // 16-byte aligned pairs: ds_read_b128
+                    const float4 *p4 = reinterpret_cast<const float4 *>(pp);
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) { const float4 v = p4[i2]; x[2 * i2] = make_float2(v.x, v.y); x[2 * i2 + 1] = make_float2(v.z, v.w); }
+                } else
 #pragma unroll
                 for (int i2 = 0; i2 < 8; ++i2) x[i2] = pp[i2];
                 const float4 *hp = reinterpret_cast<const float4 *>(h + blk * 8);
@@ -531,12 +545,18 @@ __device__ __forceinline__ void fir_tiled(const float2 *lanep, const uint32_t *j
         // lanep is the padded LDS address of sample q0*D (a multiple of the pad period), so pad(q0*D + t) =
         // pad(q0*D) + pad(t) with a wave-uniform second term; a block never straddles a pad
         const uint32_t t = c + blk * BS;
-        const float2 *pp = lanep + (t + (t >> GeoT::pshift));
-        const uint64_t *p8 = reinterpret_cast<const uint64_t *>(pp);  // one 8-byte LDS read per sample (rows are 8-byte aligned only)
+        const float2 *pp = lanep + (t + GeoT::kPad * (t >> GeoT::pshift));
+        if constexpr (GeoT::kPad == 2) {                              // 16-byte aligned pairs: ds_read_b128
+            const float4 *p4 = reinterpret_cast<const float4 *>(pp);
 #pragma unroll
-        for (int i = 0; i < BS; ++i) {
-            const uint64_t v = p8[i];
-            x[i] = make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+            for (int i = 0; i < BS / 2; ++i) { const float4 v = p4[i]; x[2 * i] = make_float2(v.x, v.y); x[2 * i + 1] = make_float2(v.z, v.w); }
+        } else {
+            const uint64_t *p8 = reinterpret_cast<const uint64_t *>(pp);  // one 8-byte LDS read per sample (rows are 8-byte aligned only)
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                const uint64_t v = p8[i];
+                x[i] = make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+            }
         }
     };
     auto load_h1 = [&](uint32_t j0, float *hh) {                   // BS taps from h + j0 (16-byte aligned broadcast reads)
@@ -632,7 +652,7 @@ __device__ __forceinline__ void fir_tiled(const float2 *lanep, const uint32_t *j
 // sets (block k+1's reads in flight while block k accumulates); a truncated output (jmax < T) is the
 // accumulator snapshot taken at tap jmax, as in fir_span.
 template <class GeoT>
-__device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const float *h) {
+__device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const float *h, float *snap_out = nullptr) {
     constexpr uint32_t D = GeoT::D, Dp = GeoT::Dp, T = GeoT::T, b = GeoT::b0;
     // PRE taps reach the first 8-aligned LDS column; from there 8-tap blocks never straddle a row (D % 8 == 0),
     // so the body is a ROLLED loop (fully unrolled, the scheduler hoists every read and spills ~150 VGPRs)
@@ -690,6 +710,7 @@ __device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const 
         if (cand(jj)) { if (jmax == jj) snap = acc; }
         acc = acc + xp[xoff(b + jj)] * h[jj];
     }
+    if (snap_out) { *snap_out = snap; return acc; }      // shared-FIR mode keeps both (dec / trc)
     return jmax < T ? snap : acc;
 }
 
@@ -881,11 +902,24 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                         }
                     }
                     float2 full[R], snp[R];
-                    fir_tiled<R, GeoT>(raw + (q0 * D + q0 / R), jm, tapl, full, snp);
+                    fir_tiled<R, GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), jm, tapl, full, snp);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (q0 + r < Q) { dec[q0 + r] = full[r]; if (jm[r] < T) trc[q0 + r] = snp[r]; }
                     }
+                }
+            } else if constexpr (GeoT::split_ok_shared((uint32_t)NT)) {
+                for (uint32_t t = tid; t < 2u * Q; t += NT) {
+                    const uint32_t qi = t >> 1, part = t & 1u;
+                    uint32_t jmax = T;
+                    if (qi + ntrunc >= W) {
+                        const uint32_t g = (qi - (W - ntrunc)) / S, k = qi - g * S;
+                        if (k < W && g < g_cnt) { const uint32_t jm = (W - k) * D + T / 2; if (jm < T) jmax = jm; }
+                    }
+                    float snapv = 0.f;
+                    const float full = fir_comp<GeoT>(reinterpret_cast<const float *>(raw + (size_t)(qi + geo.a0) * Dp) + part, jmax, tapl, &snapv);
+                    reinterpret_cast<float *>(dec + qi)[part] = full;
+                    if (jmax < T) reinterpret_cast<float *>(trc + qi)[part] = snapv;
                 }
             } else
             for (uint32_t qi = tid; qi < Q; qi += NT) {
@@ -941,7 +975,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) { const uint32_t j2 = (W - (k0 + r)) * D + T / 2; jm[r] = j2 < T ? j2 : T; }
                 float2 full[R], snp[R];
-                { const uint32_t q0 = g * S + k0; fir_tiled<R, GeoT>(raw + (q0 * D + q0 / R), jm, tapl, full, snp); }
+                { const uint32_t q0 = g * S + k0; fir_tiled<R, GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), jm, tapl, full, snp); }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t k = k0 + r;

@@ -13,14 +13,15 @@ struct FixedEntry {
     uint32_t W, S, D, T, G;
     int lb;              // register budget the build targets: waves per SIMD (4 -> 128 VGPRs, 2 -> 256)
     int nt;              // workgroup size
+    int pad;             // LDS pad elements per row (FixedGeo::kPad request: 1 or 2)
     chain_fn fn;
     const char *name;
 };
 
 #define QD_FIXED(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NAME) \
-    { F, NCO, W, S, D, T, G, LB, qd::kThreads, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
-#define QD_FIXED_NT(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, FIRR, NAME) \
-    { F, NCO, W, S, D, T, G, LB, NT, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, FIRB, FIRR>, true, RCH, WHOLE, true, LB, NT>, NAME }
+    { F, NCO, W, S, D, T, G, LB, qd::kThreads, 1, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
+#define QD_FIXED_NT(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, FIRR, PAD, NAME) \
+    { F, NCO, W, S, D, T, G, LB, NT, PAD, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, FIRB, FIRR, PAD>, true, RCH, WHOLE, true, LB, NT>, NAME }
 
 // defined in qd_longfir.hip
 const FixedEntry *longfir_entries(int *count);

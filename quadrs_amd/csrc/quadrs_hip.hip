@@ -241,7 +241,7 @@ const FixedEntry kFixed[] = {
     // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
-    QD_FIXED_NT(0, 0, 1024, 1024, 8, 512, 1, 5, true, 4, 1024, 4, 2, "cfg4"),
+    QD_FIXED_NT(0, 0, 1024, 1024, 8, 512, 1, 5, true, 4, 1024, 4, 2, 2, "cfg4"),
 };
 
 const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t D, uint32_t T) {
@@ -260,10 +260,10 @@ const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t 
 // process.  QD_JIT=0 disables, QD_JIT=1 forces it for every plan; by default only streams whose chain
 // input is >= 16 MiB pay the ~0.3 s compile.
 struct JitKey {
-    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1; int noslp = 0;
+    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1; int noslp = 0; uint32_t pad = 1;
     bool operator<(const JitKey &o) const {
-        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr, noslp) <
-               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr, o.noslp);
+        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr, noslp, pad) <
+               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr, o.noslp, o.pad);
     }
 };
 std::mutex g_jit_mu;
@@ -287,8 +287,8 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
     if (!probe) { *why = "kernel headers not found next to the library (" + dir + ")"; return nullptr; }
     fclose(probe);
     char name[512];
-    snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
-             k.S, k.D, k.T, k.G, k.firb, k.firr, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
+    snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
+             k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
     std::string src = std::string("#include \"qd_chain.h\"\ntemplate __global__ void ") + name + "(const qd::ChainParams);\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "qd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *why = "hiprtcCreateProgram failed"; return nullptr; }
@@ -330,9 +330,9 @@ struct Geometry {
     size_t lds_bytes = 0;
 };
 
-size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems) {
+size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems, uint32_t pad_per_row = 1) {
     uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
-    uint64_t pad = (D % 2 == 0) ? tile_raw / D + 1 : 0;
+    uint64_t pad = (D % 2 == 0) ? pad_per_row * (tile_raw / D + 1) : 0;
     uint64_t elems = tile_raw + pad + 1;
     uint64_t min_elems = (uint64_t)G * W / 2 + 1;     // bucket epilogue parks G*W f32 norms here
     if (elems < min_elems) elems = min_elems;
@@ -619,14 +619,14 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
                     (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
     p->fixed = (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS) ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
-    // QD_TUNE=G:NT:FIRR:FIRB:LB (development): force a plan-time build with this tiling instead of the table / heuristics
-    // (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256)
-    uint32_t tune[5] = {0, 0, 1, 8, 4};
+    // QD_TUNE=G:NT:FIRR:FIRB:LB:PAD (development): force a plan-time build with this tiling instead of the table / heuristics
+    // (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256; PAD = LDS pad elements per row)
+    uint32_t tune[6] = {0, 0, 1, 8, 4, 1};
     bool tuned = false;
     if (const char *e = getenv("QD_TUNE")) {
-        if (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && sscanf(e, "%u:%u:%u:%u:%u", &tune[0], &tune[1], &tune[2], &tune[3], &tune[4]) >= 2 && tune[4] >= 1 && tune[4] <= 8 &&
-            tune[0] >= 1 && (tune[1] == 256 || tune[1] == 512 || tune[1] == 1024) &&
-            lds_for(tune[0], p->W, p->S, p->D, T_lds, nullptr) <= kLdsMax) {
+        if (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && sscanf(e, "%u:%u:%u:%u:%u:%u", &tune[0], &tune[1], &tune[2], &tune[3], &tune[4], &tune[5]) >= 2 && tune[4] >= 1 && tune[4] <= 8 &&
+            tune[0] >= 1 && (tune[1] == 256 || tune[1] == 512 || tune[1] == 1024) && (tune[5] == 1 || tune[5] == 2) &&
+            lds_for(tune[0], p->W, p->S, p->D, T_lds, nullptr, tune[5]) <= kLdsMax) {
             tuned = true;
             p->fixed = nullptr;
         }
@@ -644,25 +644,28 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // default on six such shapes, scripts/policy_probe.py)
     const bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D;
     int jit_lb = 4, jit_noslp = 0;
+    uint32_t pad = 1;              // LDS pad elements per row the main kernel is built with (FixedGeo PAD_)
     if (heavy) {
         auto outs = [&](uint32_t g) { return p->S < p->W ? (uint64_t)(g - 1) * p->S + p->W : (uint64_t)g * p->W; };
-        while (G < 64 && outs(G + 1) <= 512 && lds_for(G + 1, p->W, p->S, p->D, T_lds, nullptr) <= kLdsMax) ++G;
+        while (G < 64 && outs(G + 1) <= 512 && lds_for(G + 1, p->W, p->S, p->D, T_lds, nullptr, pad) <= kLdsMax) ++G;
         if (p->n_windows && G > p->n_windows) G = (uint32_t)p->n_windows;
         p->nt = 512; jit_lb = 2; jit_noslp = 1;
     } else if (tuned) {
         G = tune[0];
         p->nt = (int)tune[1];
         jit_lb = (int)tune[4];
+        pad = tune[5];
     } else if (p->fixed) {
         G = p->fixed->G;
         p->nt = p->fixed->nt;
+        pad = (uint32_t)p->fixed->pad;
     } else {
         while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr) <= 40 * 1024) G *= 2;
         while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr) <= 36 * 1024) G *= 2;
         if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
     }
     p->geo.G = G;
-    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems);
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad);     // the generic kernels (pad 1) fit inside the same allocation
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
@@ -679,7 +682,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
             const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
             JitKey k{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, jit_lb, p->nt,
-                     p->W, p->S, p->D, p->T, G, tune[3], tune[2], jit_noslp};
+                     p->W, p->S, p->D, p->T, G, tune[3], tune[2], jit_noslp, pad};
             p->jit_fn = jit_chain_kernel(k, &p->jit_note);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "QD_TUNE build failed: %s", p->jit_note.c_str());
         }
