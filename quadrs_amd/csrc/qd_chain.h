@@ -1102,8 +1102,14 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             for (uint32_t o = tid; o < n_out; o += NT) {
                 const float2 xv = fb[o ^ (W >> 1)];           // fftshift: bin (b + W/2) mod W of the same window
                 const float nm = (P.dbg & 8) ? xv.x : norm_ref(xv);
-                if (P.epi == 0) outf[o] = nm;
-                else outb[o] = glyph_code(nm, P.rmin, P.rmax);
+                // The store address is uniform base + 32-bit lane offset.  Keep the offset opaque so hipcc does not
+                // hoist a per-lane 64-bit `P.out + tid*4` out of the tile loop: that pair was the kernel's one VGPR
+                // spill, and its scratch reload here carried an s_waitcnt vmcnt(0) — a full drain of the next tile's
+                // prefetch loads in every epilogue.
+                uint32_t oo = o;
+                asm volatile("" : "+v"(oo));
+                if (P.epi == 0) outf[oo] = nm;
+                else outb[oo] = glyph_code(nm, P.rmin, P.rmax);
             }
         }
         rt_touch += rt_pf;       // first use of the touch loads: a whole tile after they were issued
