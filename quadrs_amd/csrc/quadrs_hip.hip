@@ -15,6 +15,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -834,6 +835,30 @@ int qd_plan_last_kernel_ms(qd_plan *p, float *ms) {
     return QD_OK;
 }
 
+namespace {
+// Pageable -> pinned staging copy on several host threads: one thread moves ~10-15 GB/s, which would cap the
+// host-resident path far below PCIe; QD_COPY_THREADS overrides the thread count (default: up to 8).
+void par_memcpy(void *dst, const void *src, size_t n) {
+    static const unsigned n_thr = [] {
+        if (const char *e = getenv("QD_COPY_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) return (unsigned)v; }
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned t = hw / 2; if (t < 1) t = 1; if (t > 8) t = 8;
+        return t;
+    }();
+    if (n_thr <= 1 || n < (8u << 20)) { memcpy(dst, src, n); return; }
+    const size_t slice = ((n / n_thr) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < n_thr; ++i) {
+        const size_t off = i * slice;
+        if (off >= n) break;
+        const size_t len = off + slice > n ? n - off : slice;
+        th.emplace_back([=] { memcpy(static_cast<uint8_t *>(dst) + off, static_cast<const uint8_t *>(src) + off, len); });
+    }
+    memcpy(dst, src, slice < n ? slice : n);
+    for (auto &t : th) t.join();
+}
+}  // namespace
+
 int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint64_t src_count,
                 uint64_t first_window, uint64_t n_windows, void *out, int out_mem, void *stream) {
     if (!p || !src || !out) return fail(QD_ERR_INVALID, "NULL argument");
@@ -875,7 +900,7 @@ int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, ui
     auto drain = [&](int slot) -> int {
         if (!pend[slot].live) return QD_OK;
         HIPCHK(hipStreamSynchronize(p->streams[slot]));
-        memcpy(static_cast<uint8_t *>(out) + (pend[slot].w0 - first_window) * obw, p->pin_out[slot], pend[slot].nw * obw);
+        par_memcpy(static_cast<uint8_t *>(out) + (pend[slot].w0 - first_window) * obw, p->pin_out[slot], pend[slot].nw * obw);
         pend[slot].live = false;
         return QD_OK;
     };
@@ -891,7 +916,7 @@ int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, ui
         uint64_t cnta = s0 + cnt - s0a;
         if (s0a < src_first || s0a + cnta > src_first + src_count)
             return fail(QD_ERR_INVALID, "src slab does not cover the requested windows");
-        memcpy(p->pin_in[slot], static_cast<const uint8_t *>(src) + (s0a - src_first) * bps, cnta * bps);
+        par_memcpy(p->pin_in[slot], static_cast<const uint8_t *>(src) + (s0a - src_first) * bps, cnta * bps);
         HIPCHK(hipMemcpyAsync(p->dev_in[slot], p->pin_in[slot], cnta * bps, hipMemcpyHostToDevice, p->streams[slot]));
         rc = launch_chain(p, p->dev_in[slot], s0a, cnta, w, nw, w, p->dev_out[slot], p->streams[slot]);
         if (rc) return rc;
