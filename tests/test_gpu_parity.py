@@ -433,8 +433,11 @@ def test_cfg2_full_size_properties(engine, oracle):
     p.run_device(src, out)
     torch.cuda.synchronize()
     host_out = out.cpu().numpy()
+    # SURVEY §8(d) subsample: first 1 024, last 1 024, 4 096 pseudo-random windows, every 2/4/8-shard seam +-4
     rng = np.random.default_rng(0)
-    picks = sorted(set([0, 1, 2, 65532, 65533, 65534] + rng.integers(0, 65535, 40).tolist()))
+    nw = p.n_windows
+    seams = [int(b) + d for k in (2, 4, 8) for b in np.linspace(0, nw, k + 1)[1:-1] for d in range(-4, 5)]
+    picks = sorted(set(list(range(1024)) + list(range(nw - 1024, nw)) + rng.integers(0, nw, 4096).tolist() + seams))
     for w in picks:
         first, count = p.src_range(w, 1)
         slab = src[first:first + count].cpu().numpy()
@@ -461,3 +464,72 @@ def test_cfg2_full_size_properties(engine, oracle):
         p.run_device(src[first:first + count], part, w0, w1 - w0, src_first=first, src_count=count)
         torch.cuda.synchronize()
         assert torch.equal(part, out[w0:w1])
+
+
+FULL_SIZE = {
+    # name: (fmt, log2 N, sample rate, shift, (fc, D, T), W, S)  —  SURVEY §8 config table
+    "cfg3p": (0, 31, 21_000_000, 280000, (200_000, 32, 200), 128, 128),
+    "cfg3": (1, 33, 21_000_000, 280000, (200_000, 32, 400), 64, 16),
+    "cfg4": (0, 32, 100_000_000, None, (5_000_000, 8, 512), 1024, 1024),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE))
+def test_full_size_chains(engine, oracle, name):
+    """BASELINE configs[2], [3] and the north_star target chain at FULL size (16 / 16 / 32 GiB resident in HBM):
+    the oracle on a window subsample (head, tail, random, 2/4/8-shard seams), the SURVEY section 8 size rows,
+    idempotence, and two-shard concatenation with the halo."""
+    import torch
+    fmt, lg, sr, shift, lp, W, S = FULL_SIZE[name]
+    N = 1 << lg
+    free, _ = torch.cuda.mem_get_info()
+    need = N * (8 if fmt == 0 else 2) * 1.3
+    if free < need:
+        pytest.skip(f"{name}: needs {need / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} free")
+    g = torch.Generator(device="cuda"); g.manual_seed(lg)
+    if fmt == 0:
+        src = torch.empty(N, 2, device="cuda", dtype=torch.float32)
+        step = 1 << 28
+        for a in range(0, N, step):            # in pieces: randn's temporaries stay small
+            src[a:a + step].normal_(0.0, 0.02, generator=g)
+    else:
+        src = torch.randint(-128, 128, (N, 2), device="cuda", dtype=torch.int8, generator=g)
+    p = engine.Plan(fmt, sr, N, shift_hz=shift, lowpass=lp, width=W, stride=S)
+    D, T = lp[1], lp[2]
+    L = 1 + (N - T) // D
+    assert p.info.decimated_len == L and p.n_windows == (0 if L <= W else (L - W - 1) // S + 1)
+    nw = p.n_windows
+    assert nw == {"cfg3p": 524287, "cfg3": 16777212, "cfg4": 524287}[name]            # SURVEY section 8 table
+    out = torch.empty(nw, W, device="cuda", dtype=torch.float32)
+    p.run_device(src, out)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(lg)
+    seams = [int(b) + d for k in (2, 4, 8) for b in np.linspace(0, nw, k + 1)[1:-1] for d in range(-2, 3)]
+    picks = sorted(set(list(range(24)) + list(range(nw - 24, nw)) + rng.integers(0, nw, 96).tolist() + seams))
+    taps = oracle.taps(lp[0], sr, T)
+    ratio = oracle.shift_ratio(shift, sr) if shift is not None else None
+    for w in picks:
+        first, count = p.src_range(w, 1)
+        raw = src[first:first + count].cpu().numpy()
+        x = raw if fmt == 0 else oracle.unpack(fmt, raw.tobytes())
+        if ratio is not None:
+            x = oracle.shift_apply(x, first, ratio)
+        n_out, dec = oracle.lowpass_block(taps, D, x)
+        assert n_out == W
+        ref = oracle.norm(oracle.fft(dec))[np.r_[W // 2:W, 0:W // 2]]
+        assert_norms_close(ref[None], out[w].cpu().numpy()[None], f"{name} window {w}")
+    # idempotence
+    out2 = torch.empty_like(out)
+    p.run_device(src, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    del out2
+    # two shards, each from its own slab + halo, concatenate to the whole
+    half = (nw // 2 // p.info.tile_windows) * p.info.tile_windows
+    for w0, w1 in ((0, half), (half, nw)):
+        first, count = p.src_range(w0, w1 - w0)
+        part = torch.empty(w1 - w0, W, device="cuda", dtype=torch.float32)
+        p.run_device(src[first:first + count], part, w0, w1 - w0, src_first=first, src_count=count)
+        torch.cuda.synchronize()
+        assert torch.equal(part, out[w0:w1])
+        del part
