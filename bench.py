@@ -34,7 +34,7 @@ WORKLOADS = {
     "cfg3": dict(fmt=1, n=1 << 33, sr=21_000_000, shift=280000, lp=(200_000, 32, 400), W=64, S=16,
                  desc="16 GiB cs8: unpack -> shift -> lowpass -power 200 -decimate 32 200000 -> sparkfft -width 64 -stride 16"),
     "cfg4": dict(fmt=0, n=1 << 32, sr=100_000_000, shift=None, lp=(5_000_000, 8, 512), W=1024, S=1024,
-                 desc="32 GiB cf32 (gen-like): 512-tap FIR decimate 8 -> 1024-pt FFT"),
+                 desc="gen 64 cosines @100 Msps, 32 GiB cf32: 512-tap FIR decimate 8 -> 1024-pt FFT"),
 }
 BPS = {0: 8, 1: 2, 2: 2, 3: 4}
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E data-sheet peak (MI355X_MICROARCH.md); ~6300 measured copy
@@ -150,7 +150,16 @@ def main():
     shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, info.tile_windows)
     me = shards[rank]
 
-    own = synth_slab(torch, fmt, me.own_first, me.own_count, 0x5EED0002 + rank, device)
+    if args.workload == "cfg4":
+        # configs[3]: `gen` with 64 cosines @100 Msps (f_k = (k-32)*1 562 500 + 390 625 Hz), generated on
+        # the device by the engine's own Gen kernel, outside the timed region
+        own = torch.empty(me.own_count, 2, dtype=torch.float32, device=device)
+        tones = [(k - 32) * 1_562_500 + 390_625 for k in range(64)]
+        piece = 1 << 28
+        for a in range(0, me.own_count, piece):
+            Q.gen_device(tones, cfg["sr"], me.own_first + a, own[a:a + piece])
+    else:
+        own = synth_slab(torch, fmt, me.own_first, me.own_count, 0x5EED0002 + rank, device)
     own_u8 = own.view(torch.uint8).reshape(-1)
     if world == 1:
         slab = own_u8

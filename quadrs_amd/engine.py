@@ -85,6 +85,16 @@ def gen(cos_hz, sample_rate, first, n):
     return out
 
 
+def gen_device(cos_hz, sample_rate, first, out):
+    """Gen::read_at (src/gen.rs:35-47) straight into a device buffer: `out` is a float32 (n,2) torch tensor on the GPU
+    (the `gen ... | lowpass | sparkfft` chains of BASELINE configs[3] never cross PCIe)."""
+    cos = np.ascontiguousarray(cos_hz, dtype=np.int64)
+    assert _is_torch(out) and out.is_cuda and out.is_contiguous() and out.dtype.itemsize == 4
+    n = out.numel() // 2
+    check(lib().qd_gen(_np_ptr(cos), cos.size, int(sample_rate), int(first), n, C.c_void_p(out.data_ptr()), MEM_DEVICE))
+    return out
+
+
 def take_fft(x, width, output_len, slice_=None, windowing=1, in_first=0, samples_len=None):
     """take_fft (src/ffts.rs:18-85) over cf32 samples x = samples [in_first, in_first+len(x)) of the viewed stream."""
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 2)
