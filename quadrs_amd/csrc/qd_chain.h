@@ -76,7 +76,7 @@ struct ChainParams {
     float root2;
     float2 tw16_1, tw16_2, tw16_3;
     uint32_t epi;              // qd_epilogue
-    uint32_t dbg;              // timing-only ablation bits (QD_DEBUG_SKIP); 0 in every real run
+    uint32_t dbg;              // timing-only ablation bits (QD_DEBUG_SKIP; 1 NCO, 2 FIR, 4 FFT, 8 hypot, 16 output store, 32 LDS staging); 0 in every real run
     unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
     const uint64_t *row_offsets; // take_fft (src/ffts.rs:59-60): window w starts at row_offsets[w] (generic kernels, G = 1)
     const float *window;         // take_fft windowing (src/ffts.rs:64-68): sample k of a window is scaled by window[k]
@@ -330,6 +330,10 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
     // Additive addressing: rel is a multiple of PD (n_start and ROW both are) and SPL divides PD, so
     // pad(rel + t) = pad_s(rel) + pad(t) and a lane's SPL samples are contiguous in LDS.
     const bool additive = geo.pshift != 0xffffffffu && geo.PD >= (uint32_t)SPL && geo.PD <= ROW;
+    if (P.dbg & 32) {            // timing-only ablation: consume the row without the LDS store
+        asm volatile("" :: "v"(x[0].x), "v"(x[0].y), "v"(x[SPL - 1].x), "v"(x[SPL - 1].y));
+        return;
+    }
     if (additive) {
         const int32_t row_pad = rel + ((geo.Dp != geo.D) ? (int32_t)geo.kPad * (rel >> geo.pshift) : 0);      // uniform, signed
         float2 *dst = raw + (row_pad + (int32_t)lane_pad);
@@ -1108,6 +1112,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 // prefetch loads in every epilogue.
                 uint32_t oo = o;
                 asm volatile("" : "+v"(oo));
+                if (P.dbg & 16) { asm volatile("" :: "v"(nm)); continue; }      // timing-only ablation: no output store
                 if (P.epi == 0) outf[oo] = nm;
                 else outb[oo] = glyph_code(nm, P.rmin, P.rmax);
             }
