@@ -814,7 +814,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         // ---------------- phase 1: HBM -> unpack -> NCO -> LDS
         double rt_pf = 0.0;
         // Wave priority: the arithmetic phases sit on the workgroup's barrier chain, phase 1 mostly waits for HBM,
-        // so a wave in FIR / FFT / epilogue is issued ahead of the other workgroups' phase-1 waves (2-4 % on cfg2).
+        // so a wave in FIR (1) / FFT + epilogue (3) is issued ahead of the other workgroups' phase-1 waves (0): the
+        // closer a workgroup is to finishing its tile, the sooner it gets issue slots (cfg3' +7 %, cfg2 +2-4 %;
+        // scripts/prio_probe.py).
         __builtin_amdgcn_s_setprio(0);
         if constexpr (kReloadLane) {
             uint32_t first = tid * SPL;
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         __syncthreads();
         QD_STAMP_AT(1);
 
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(1);
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
         const uint32_t n_out = g_cnt << logW;
         const uint32_t log_width = 2 * geo.layers;   // width = W / base_len = 4^layers
@@ -1029,6 +1031,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         __syncthreads();
         QD_STAMP_AT(3);
 
+        __builtin_amdgcn_s_setprio(3);
         // ---------------- phase 3: FFT (rustfft Radix4: base butterflies, then radix-4 layers)
         if (!(P.dbg & 4) && !cf32_out) {
             const uint32_t base = geo.base_len;
