@@ -1126,7 +1126,10 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         }
         rt_touch += rt_pf;       // first use of the touch loads: a whole tile after they were issued
         QD_STAMP_AT(6);
-        __syncthreads();
+        // No barrier here for the norm / glyph / cf32 epilogues: they only read fb, the next tile's phase 1 only
+        // writes the raw region, and barrier 1 of the next tile orders everything before fb (or dec/trc) is
+        // written again.  The bucket epilogue parks its norms IN the raw region, so it keeps the barrier.
+        if (P.epi == 2) __syncthreads();
         QD_STAMP_AT(7);
         QD_STAMP_TILE();
         walk_local += walk_step;

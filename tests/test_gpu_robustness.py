@@ -3,6 +3,8 @@ concurrent use of one plan, degenerate sizes."""
 import ctypes as C
 import threading
 
+import os
+
 import numpy as np
 import pytest
 
@@ -147,6 +149,8 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     """hiprtc: the same kernel source with the plan's geometry as compile-time constants must give
     the generic kernel's bits (and the oracle's)."""
     from test_gpu_parity import _signal, _to_format, assert_norms_close
+    if os.environ.get("QD_NO_FIXED"):
+        pytest.skip("QD_NO_FIXED=1 runs the generic kernels only (no plan-time builds)")
     N = 300_000
     data = _to_format(_signal(np.random.default_rng(W), N), fmt)
     plans = {}
