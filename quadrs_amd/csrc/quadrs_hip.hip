@@ -302,6 +302,15 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
 #endif
     std::vector<const char *> optv(opts, opts + sizeof opts / sizeof opts[0]);
     if (k.noslp || getenv("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");   // scalar f32 accumulate chains (see qd_longfir.hip)
+    std::vector<std::string> extra;                          // development: QD_JIT_FLAGS="-mllvm -foo ..." appended verbatim
+    if (const char *e = getenv("QD_JIT_FLAGS")) {
+        std::string cur;
+        for (const char *c = e;; ++c) {
+            if (*c == ' ' || *c == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*c) break; }
+            else cur.push_back(*c);
+        }
+        for (const std::string &x : extra) optv.push_back(x.c_str());
+    }
     hiprtcResult r = hiprtcCompileProgram(prog, (int)optv.size(), optv.data());
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
@@ -315,6 +324,9 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
     size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
     std::vector<char> code(cs);
     hiprtcGetCode(prog, code.data());
+    if (const char *dump = getenv("QD_JIT_DUMP")) {          // development: keep the code object for llvm-objdump
+        if (FILE *f = fopen(dump, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+    }
     hipModule_t mod; hipFunction_t fn = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess || !lowered || hipModuleGetFunction(&fn, mod, lowered) != hipSuccess) {
         *why = "hipModuleLoadData / GetFunction failed";
