@@ -433,15 +433,20 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                 accr = accr + x[6].x * hh[1].z; acci = acci + x[6].y * hh[1].z;
                 accr = accr + x[7].x * hh[1].w; acci = acci + x[7].y * hh[1].w;
             };
+            // branch-free body in pairs (the scheduler is kept from hoisting set A's reload above its last use, which
+            // would cost a register copy of the whole set at the back edge); an odd last block is peeled
             load_blk(0, xa, ha);
-            for (uint32_t blk = 0; blk < nblk; blk += 2) {
-                if (blk + 1 < nblk) load_blk(blk + 1, xb, hb);
+            uint32_t blk = 0;
+            for (; blk + 2 < nblk; blk += 2) {
+                load_blk(blk + 1, xb, hb);
                 mac_blk(blk, xa, ha);
-                if (blk + 1 < nblk) {
-                    if (blk + 2 < nblk) load_blk(blk + 2, xa, ha);
-                    mac_blk(blk + 1, xb, hb);
-                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_blk(blk + 2, xa, ha);
+                mac_blk(blk + 1, xb, hb);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (blk + 1 < nblk) { load_blk(blk + 1, xb, hb); mac_blk(blk, xa, ha); mac_blk(blk + 1, xb, hb); }
+            else mac_blk(blk, xa, ha);
         } else if (n > 256 && GeoT::kFirBlock >= 8) {
             // very long filters: a ROLLED loop over LDS rows (D taps each) with an 8-tap inner unroll —
             // fully unrolling 400-500 taps blows the register allocator up.  A lane's jmax can only be
