@@ -437,7 +437,8 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
             // would cost a register copy of the whole set at the back edge); an odd last block is peeled
             load_blk(0, xa, ha);
             uint32_t blk = 0;
-            for (; blk + 2 < nblk; blk += 2) {
+#pragma unroll 1
+            for (; blk + 2 < nblk; blk += 2) {      // never fully unrolled: at T = 800 that spills ~1900 VGPRs
                 load_blk(blk + 1, xb, hb);
                 mac_blk(blk, xa, ha);
                 __builtin_amdgcn_sched_barrier(0);
@@ -701,15 +702,21 @@ __device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const 
     constexpr uint32_t NPAIR = NBLK / 2;                                   // blocks [0, 2*NPAIR) in ping-pong pairs
     load(0, xa, ha);
     // unroll explicitly: hipcc fully unrolls this loop for T = 200 on its own, hiprtc does not (10 % slower kernel)
-    constexpr int kUnroll = NPAIR <= 16 ? (int)NPAIR : 4;
-#pragma unroll kUnroll
-    for (uint32_t m = 0; m + 2 < 2 * NPAIR; m += 2) {
+    auto pair = [&](uint32_t m) {
         load(m + 1, xb, hb);
         mac(m, xa, ha);
         __builtin_amdgcn_sched_barrier(0);      // set A is reloaded only below its last use: no copies at the back edge
         load(m + 2, xa, ha);
         mac(m + 1, xb, hb);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (NPAIR <= 16) {
+#pragma unroll
+        for (uint32_t m = 0; m + 2 < 2 * NPAIR; m += 2) pair(m);
+    } else {
+#pragma unroll 1
+        for (uint32_t m = 0; m + 2 < 2 * NPAIR; m += 2) pair(m);      // longer filters stay rolled (a full unroll of T = 800 spills ~1900 VGPRs;
+                                                                       // `#pragma unroll 2` is unrolled again, fully, by a later pass)
     }
     load(2 * NPAIR - 1, xb, hb);
     mac(2 * NPAIR - 2, xa, ha);

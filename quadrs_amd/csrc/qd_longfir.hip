@@ -10,10 +10,11 @@
 // -fno-slp-vectorize.
 //
 // Tiling: the FIR phase of a tile is latency-bound (one wave walks all T taps however few outputs the
-// tile has), so these shapes take the largest tile LDS allows: 28 windows of 64 = 496 FIR outputs for 512
-// lanes, one 156 KiB tile per CU, 256-VGPR budget (no spills in the tap loop).  The 16-byte-aligned LDS layout
-// (PAD 2, ds_read_b128 pairs) was measured here too: it costs a window of tile (27 instead of 28 fit) and the
-// tap loop is not LDS-throughput-bound (19.1k vs 20.3k cycles for 480 vs 496 outputs), so PAD stays 1.
+// tile has), so these shapes take the largest tile LDS allows: 27 windows of 64 = 480 FIR outputs for 512
+// lanes, one ~156 KiB tile per CU, 256-VGPR budget (no spills in the tap loop).  LDS rows are 16-byte aligned
+// (PAD 2): the tap loop reads sample pairs with conflict-free ds_read_b128 instead of the ds_read2_b64 hipcc forms
+// from 8-byte reads (half the bytes per clock on gfx950); that costs one window of tile (27 instead of 28 fit) and
+// is worth 4 % once the loop itself is tight (33.7 -> 32.3 ms on cfg3).
 #include "qd_registry.h"
 
 namespace qd {
@@ -21,12 +22,12 @@ namespace qd {
 static const FixedEntry kLongFir[] = {
     // README.md:90-94 / configs[2]  "lowpass -power 200 -decimate 32 200000 | sparkfft -width 64 -stride 16"
     // cf32 input (the README's own FSK example file): 1024-sample rows, 17 per tile -> chunked prefetch
-    QD_FIXED_NT(0, 1, 64, 16, 32, 400, 28, 4, false, 2, 512, 8, 1, 1, "fsk5"),
-    QD_FIXED_NT(0, 2, 64, 16, 32, 400, 28, 4, false, 2, 512, 8, 1, 1, "fsk5"),
+    QD_FIXED_NT(0, 1, 64, 16, 32, 400, 27, 4, false, 2, 512, 8, 1, 2, "fsk5"),
+    QD_FIXED_NT(0, 2, 64, 16, 32, 400, 27, 4, false, 2, 512, 8, 1, 2, "fsk5"),
 #ifndef QD_DEV_FAST
     // cs8 input (HackRF): 2048-sample rows, 9 per tile, whole-tile register prefetch
-    QD_FIXED_NT(1, 1, 64, 16, 32, 400, 28, 9, true, 2, 512, 8, 1, 1, "cfg3"),
-    QD_FIXED_NT(1, 2, 64, 16, 32, 400, 28, 9, true, 2, 512, 8, 1, 1, "cfg3"),
+    QD_FIXED_NT(1, 1, 64, 16, 32, 400, 27, 9, true, 2, 512, 8, 1, 2, "cfg3"),
+    QD_FIXED_NT(1, 2, 64, 16, 32, 400, 27, 9, true, 2, 512, 8, 1, 2, "cfg3"),
 #endif
 };
 

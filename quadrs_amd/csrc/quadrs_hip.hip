@@ -660,6 +660,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     uint32_t pad = 1;              // LDS pad elements per row the main kernel is built with (FixedGeo PAD_)
     if (heavy) {
         auto outs = [&](uint32_t g) { return p->S < p->W ? (uint64_t)(g - 1) * p->S + p->W : (uint64_t)g * p->W; };
+        pad = 2;                   // 16-byte aligned LDS rows: ds_read_b128 sample pairs in the tap loop (FixedGeo::kPad)
         while (G < 64 && outs(G + 1) <= 512 && lds_for(G + 1, p->W, p->S, p->D, T_lds, nullptr, pad) <= kLdsMax) ++G;
         if (p->n_windows && G > p->n_windows) G = (uint32_t)p->n_windows;
         p->nt = 512; jit_lb = 2; jit_noslp = 1;
