@@ -10,8 +10,9 @@
 // -fno-slp-vectorize.
 //
 // Tiling: the FIR phase of a tile is latency-bound (one wave walks all T taps however few outputs the
-// tile has), so these shapes take the largest tile LDS allows: 27 windows of 64 = 480 FIR outputs for 512
-// lanes, one ~156 KiB tile per CU, 256-VGPR budget (no spills in the tap loop).  LDS rows are 16-byte aligned
+// tile has), so these shapes take the largest tile LDS allows: 27 windows of 64 = 480 FIR outputs, one ~156 KiB
+// tile per CU.  1024 threads: the FIR keeps 8 of the 16 waves busy, but phase 1 (unpack + f64 NCO over 15 792 samples,
+// 40 % of the tile) runs on all 16 (31.1 ms vs 32.3 ms with 512 threads and a 256-VGPR budget).  LDS rows are 16-byte aligned
 // (PAD 2): the tap loop reads sample pairs with conflict-free ds_read_b128 instead of the ds_read2_b64 hipcc forms
 // from 8-byte reads (half the bytes per clock on gfx950); that costs one window of tile (27 instead of 28 fit) and
 // is worth 4 % once the loop itself is tight (33.7 -> 32.3 ms on cfg3).
@@ -21,13 +22,13 @@ namespace qd {
 
 static const FixedEntry kLongFir[] = {
     // README.md:90-94 / configs[2]  "lowpass -power 200 -decimate 32 200000 | sparkfft -width 64 -stride 16"
-    // cf32 input (the README's own FSK example file): 1024-sample rows, 17 per tile -> chunked prefetch
-    QD_FIXED_NT(0, 1, 64, 16, 32, 400, 27, 4, false, 2, 512, 8, 1, 2, "fsk5"),
-    QD_FIXED_NT(0, 2, 64, 16, 32, 400, 27, 4, false, 2, 512, 8, 1, 2, "fsk5"),
+    // cf32 input (the README's own FSK example file): 2048-sample rows, 9 per tile
+    QD_FIXED_NT(0, 1, 64, 16, 32, 400, 27, 9, true, 4, 1024, 8, 1, 2, "fsk5"),
+    QD_FIXED_NT(0, 2, 64, 16, 32, 400, 27, 9, true, 4, 1024, 8, 1, 2, "fsk5"),
 #ifndef QD_DEV_FAST
-    // cs8 input (HackRF): 2048-sample rows, 9 per tile, whole-tile register prefetch
-    QD_FIXED_NT(1, 1, 64, 16, 32, 400, 27, 9, true, 2, 512, 8, 1, 2, "cfg3"),
-    QD_FIXED_NT(1, 2, 64, 16, 32, 400, 27, 9, true, 2, 512, 8, 1, 2, "cfg3"),
+    // cs8 input (HackRF): 4096-sample rows, 5 per tile, whole-tile register prefetch
+    QD_FIXED_NT(1, 1, 64, 16, 32, 400, 27, 5, true, 4, 1024, 8, 1, 2, "cfg3"),
+    QD_FIXED_NT(1, 2, 64, 16, 32, 400, 27, 5, true, 4, 1024, 8, 1, 2, "cfg3"),
 #endif
 };
 
