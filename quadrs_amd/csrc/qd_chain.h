@@ -32,7 +32,7 @@ namespace qd {
 #define QD_STAMP_ROW(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_row[k] += t_ - st_prev; st_acc[0] += t_ - st_prev; st_prev = t_; } while (0)
 #define QD_STAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); } while (0)
 #define QD_STAMP_AT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 256) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 1) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[33 + k_], st_row[k_]); if (w_ == 0) atomicAdd(&P.stamps[32], (unsigned long long)st_tiles); } } while (0)
+#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 1024) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 1) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[129 + k_], st_row[k_]); if (w_ == 0) atomicAdd(&P.stamps[128], (unsigned long long)st_tiles); } } while (0)
 #define QD_STAMP_TILE() do { ++st_tiles; } while (0)
 #else
 #define QD_STAMP_DECL
@@ -150,6 +150,11 @@ struct FixedGeo {
     static constexpr bool split_ok(uint32_t nt) {
         return !kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * G_ * W_ <= nt;
     }
+    // register-tiled kernels: spare waves take the truncated tails (fir_prefix) when main lanes fill whole waves
+    static constexpr bool helper_ok(uint32_t nt) {
+        return kFirTile > 1 && !kShared && (G_ * W_ / kFirTile) % 64 == 0 && G_ * W_ / kFirTile + G_ * kNtrunc <= nt &&
+               (T_ / 2) % 8 == 0 && kNtrunc > 0 && kNtrunc < W_;
+    }
     static constexpr bool split_ok_shared(uint32_t nt) {      // same, shared-FIR mode: (G-1)*S + W outputs per tile
         return kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * ((G_ - 1) * S_ + W_) <= nt;
     }
@@ -160,6 +165,7 @@ struct DynGeo {
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
     static constexpr bool split_ok(uint32_t) { return false; }
+    static constexpr bool helper_ok(uint32_t) { return false; }
     static constexpr bool split_ok_shared(uint32_t) { return false; }
     uint32_t W, S, D, T, G, logW, Dp, kPad, dshift, dmagic, PD, pshift, a0, b0, T_fast, a1, b1, log_base, base_len, layers, lds_raw_elems;
     __device__ __forceinline__ explicit DynGeo(const ChainParams &P)
@@ -733,6 +739,49 @@ __device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const 
     return jmax < T ? snap : acc;
 }
 
+// Truncated tail outputs on spare lanes (register-tiled kernels whose workgroup has idle waves in the FIR phase):
+// the reference's per-read_at truncation makes the last kNtrunc outputs of a window PREFIXES of the full chain
+// (jmax = T/2 + m*D taps).  Computing them as accumulator snapshots inside the main loop makes the one wave that
+// owns them the straggler of the phase (cfg4); here an otherwise idle wave computes each prefix directly, ascending
+// taps, same products — and the main waves carry no snapshot logic at all.  (The helper's SIMD still ends ~15 %
+// after the others: two main waves already saturate a SIMD's VALU, the prefixes add 1008 packed ops to one of them.)  t0 = tile-relative index of the output's first sample (a multiple of 8); jmax is a multiple
+// of 8 (T/2 and D are), so a lane is in or out of a whole 8-tap block.
+template <class GeoT>
+__device__ __forceinline__ float2 fir_prefix(const float2 *raw, uint32_t t0, uint32_t jmax, const float *h) {
+    constexpr uint32_t T = GeoT::T;
+    float ar = 0.f, ai = 0.f;
+    uint32_t jhi = jmax;                                   // longest prefix in the wave bounds the loop
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)jhi, off); jhi = o > jhi ? o : jhi; }
+    float2 xa[8], xb[8]; float ha[8], hb[8];
+    auto load = [&](uint32_t jb, float2 *x, float *hh) {   // reads past a lane's own jmax stay inside its T-sample span
+        const uint32_t t = t0 + jb;
+        const float2 *pp = raw + (t + GeoT::kPad * (t >> GeoT::pshift));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = pp[i];
+        const float4 *hp = reinterpret_cast<const float4 *>(h + jb);
+        const float4 h0 = hp[0], h1 = hp[1];
+        hh[0] = h0.x; hh[1] = h0.y; hh[2] = h0.z; hh[3] = h0.w; hh[4] = h1.x; hh[5] = h1.y; hh[6] = h1.z; hh[7] = h1.w;
+    };
+    auto mac = [&](uint32_t jb, const float2 *x, const float *hh) {
+        if (jb < jmax) {                                   // whole block in or out (jmax is a multiple of 8)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ar = ar + x[i].x * hh[i]; ai = ai + x[i].y * hh[i]; }
+        }
+    };
+    load(0, xa, ha);
+#pragma unroll 1
+    for (uint32_t jb = 0; jb < jhi; jb += 16) {            // two 8-tap blocks per trip, the next one always in flight
+        if (jb + 8 < T) load(jb + 8, xb, hb);
+        mac(jb, xa, ha);
+        __builtin_amdgcn_sched_barrier(0);
+        if (jb + 16 < T) load(jb + 16, xa, ha);
+        mac(jb + 8, xb, hb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return make_float2(ar, ai);
+}
+
 // ---------------------------------------------------------------- the kernel
 // RCH / WHOLE: prefetch geometry.
 //   WHOLE (rows per tile <= RCH): slot i holds row i of the workgroup's *next* tile; it is refilled
@@ -990,6 +1039,39 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 const float v = (P.dbg & 2) ? xp[0] : fir_comp<GeoT>(xp, jmax, tapl);     // dbg: timing-only ablation
                 const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
                 reinterpret_cast<float *>(fb + (g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base))[part] = v;
+            }
+        } else
+        if constexpr (GeoT::kFixed && !GeoT::kShared && GeoT::kFirTile > 1 && HAS_FIR && GeoT::helper_ok((uint32_t)NT)) {
+            // main lanes: R outputs each, no truncation logic; spare waves: the truncated tails as direct prefixes
+            constexpr int R = (int)GeoT::kFirTile;
+            constexpr uint32_t NTR = GeoT::kNtrunc, n_main_max = GeoT::G * GeoT::W / R;
+            if (tid < n_main_max) {
+                const uint32_t o0 = tid * R;
+                if (o0 < n_out) {
+                    const uint32_t g = o0 >> logW, k0 = o0 & (W - 1);
+                    uint32_t jm[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) jm[r] = T;
+                    float2 full[R], snp[R];
+                    { const uint32_t q0 = g * S + k0; fir_tiled<R, GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), jm, tapl, full, snp); }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t k = k0 + r;
+                        if (k + NTR < W) {                               // the truncated ones belong to the helper lanes
+                            const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                            fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = full[r];
+                        }
+                    }
+                }
+            } else {
+                const uint32_t hidx = tid - n_main_max;
+                if (NTR > 0 && hidx < g_cnt * NTR) {
+                    const uint32_t g = hidx / NTR, k = W - NTR + hidx % NTR;
+                    const uint32_t jmax = (W - k) * D + T / 2;           // < T for these k
+                    const float2 v = fir_prefix<GeoT>(raw, (g * S + k) * D + GeoT::c, jmax, tapl);
+                    const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                    fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
+                }
             }
         } else
         if constexpr (GeoT::kFixed && !GeoT::kShared && GeoT::kFirTile > 1 && HAS_FIR) {

@@ -477,8 +477,8 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     if (const char *e = getenv("QD_DEBUG_SKIP")) P.dbg = (uint32_t)atoi(e);   // timing-only ablation, never set in tests/bench
 #ifdef QD_STAMP
     static unsigned long long *stamps_d = nullptr;
-    if (!stamps_d) { HIPCHK(hipMalloc(&stamps_d, 40 * 8)); }
-    HIPCHK(hipMemsetAsync(stamps_d, 0, 40 * 8, st));
+    if (!stamps_d) { HIPCHK(hipMalloc(&stamps_d, 160 * 8)); }
+    HIPCHK(hipMemsetAsync(stamps_d, 0, 160 * 8, st));
     P.stamps = stamps_d;
 #endif
 
@@ -526,20 +526,21 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
 #ifdef QD_STAMP
     {
-        unsigned long long h[40];
+        unsigned long long h[160];
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipMemcpy(h, P.stamps, sizeof h, hipMemcpyDeviceToHost));
         static const char *names[8] = {"phase1", "bar1", "fir", "bar2", "fft", "bar3", "epilogue", "bar4"};
-        double tiles = (double)h[32];
+        double tiles = (double)h[128];
         unsigned grid_wgs = (unsigned)(((n_windows + P.G - 1) / P.G) < cap ? ((n_windows + P.G - 1) / P.G) : cap);
         fprintf(stderr, "[stamps] tiles/launch %.0f (wgs %u): cycles per tile per wave:", tiles, grid_wgs);
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < 16; ++w) {
+            if (w >= 4 && h[w * 8] == 0) continue;                 // workgroups with fewer waves
             fprintf(stderr, "\n   wave%d:", w);
             double tot = 0;
             for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s=%.0f", names[k], h[w * 8 + k] / tiles); tot += h[w * 8 + k] / tiles; }
             fprintf(stderr, "  total=%.0f", tot);
         }
-        fprintf(stderr, "\n   wave1 phase-1 split per tile: wait_data=%.0f issue_prefetch=%.0f wait_rowbase=%.0f process=%.0f\n", h[33] / tiles, h[34] / tiles, h[35] / tiles, h[36] / tiles);
+        fprintf(stderr, "\n   wave1 phase-1 split per tile: wait_data=%.0f issue_prefetch=%.0f wait_rowbase=%.0f process=%.0f\n", h[129] / tiles, h[130] / tiles, h[131] / tiles, h[132] / tiles);
     }
 #endif
     return QD_OK;
