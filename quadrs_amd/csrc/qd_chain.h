@@ -119,7 +119,8 @@ struct FixedGeo {
     // outputs per lane in the FIR (register tiling): each LDS sample read feeds FIRR_ accumulators.
     // Needs 8-aligned geometry; falls back to 1 otherwise.
     static constexpr uint32_t kFirTile = (FIRR_ > 1 && D_ % 8 == 0 && ((T_ - T_ / 2) % D_) % 8 == 0 && T_ % 8 == 0 && (T_ / 2) % 8 == 0 &&
-                                          W_ % FIRR_ == 0 && S_ % FIRR_ == 0 && ct_pow2(D_) && ct_pow2(FIRR_)) ? FIRR_ : 1;
+                                          W_ % FIRR_ == 0 && S_ % FIRR_ == 0 && ct_pow2(D_) && ct_pow2(FIRR_) &&
+                                          T_ > (FIRR_ - 1) * D_ + 8) ? FIRR_ : 1;      // at least three interior 4-sample blocks
     // LDS pad period: one pad element per PD samples.  PD = D for the lane-per-output FIR (lane stride D + 1:
     // odd, conflict-free ds_read_b64); the register-tiled FIR strides lanes by kFirTile rows, so it pads once
     // per kFirTile * D samples to keep the lane stride odd.

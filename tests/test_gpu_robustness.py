@@ -167,3 +167,15 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
         ch = ch.lowpass(*lp)
     ref, _ = ch.spark_fft(W, S, max_windows=300)
     assert_norms_close(ref, b[:ref.shape[0]], "jit")
+
+
+def test_random_shapes_specialised_equals_generic(engine):
+    """Fuzz: ~30 random chain shapes (all four formats, odd decimations, overlapping / gapped windows, 2..800 taps,
+    some forced onto the register-tiled / wide-workgroup / 16-byte-row variants) — the plan-time specialised kernel
+    must reproduce the generic kernel bit for bit, or both must refuse the shape."""
+    if os.environ.get("QD_NO_FIXED"):
+        pytest.skip("QD_NO_FIXED=1 runs the generic kernels only")
+    import quadrs_amd as Q
+    from util import fuzz_chain_shapes
+    checked, bad = fuzz_chain_shapes(Q, 36, 20260101)
+    assert checked >= 25 and not bad, bad

@@ -46,3 +46,60 @@ def complex_ulp_err(ref, got):
 
 def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def fuzz_chain_shapes(Q, n_shapes, seed, log=None):
+    """Random chain shapes through the plan-time compiler (QD_JIT=1; a quarter of them with a QD_TUNE tiling that
+    exercises the register-tiled FIR / 16-byte LDS rows / wide workgroups) against the generic kernel (QD_JIT=0),
+    bit for bit.  Returns (checked, mismatching descriptions).  Q is the quadrs_amd package."""
+    import os
+    rng = np.random.default_rng(seed)
+    checked, bad = 0, []
+    saved = {k: os.environ.get(k) for k in ("QD_TUNE", "QD_JIT")}
+    try:
+        for _ in range(n_shapes):
+            fmt = int(rng.integers(0, 4))
+            W = 1 << int(rng.integers(2, 11))
+            S = int(rng.choice([W, W, max(1, W // 2), max(1, W // 4), int(rng.integers(1, 2 * W + 1))]))
+            D = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 32, 64]))
+            T = int(rng.choice([2, 8, 9, 16, 40, 48, 64, 100, 128, 200, 256, 400, 512, 800]))
+            if (W * D + T) * 8 * 1.2 > 150 * 1024:
+                continue
+            shift = None if rng.random() < 0.25 else int(rng.integers(-3_000_000, 3_000_000))
+            N = (int(rng.integers(3, 400)) * S + W) * D + T + int(rng.integers(0, D + 1))
+            bps = {0: 8, 1: 2, 2: 2, 3: 4}[fmt]
+            data = rng.integers(0, 256, N * bps, dtype=np.uint8)
+            if fmt == 0:
+                data = (rng.standard_normal((N, 2)).astype(np.float32) * 0.05).view(np.uint8).reshape(-1)
+            tune = None
+            if rng.random() < 0.25 and D % 8 == 0 and T % 16 == 0:
+                tune = "%d:%d:%d:8:%d:%d" % (rng.integers(1, 4), rng.choice([256, 512, 1024]), rng.choice([1, 2]), rng.choice([2, 4]),
+                                            rng.choice([1, 2]))
+            outs, info = {}, {}
+            for mode in ("0", "1"):
+                os.environ.pop("QD_TUNE", None)
+                os.environ["QD_JIT"] = mode
+                if mode == "1" and tune:
+                    os.environ["QD_TUNE"] = tune
+                try:
+                    p = Q.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=(1_000_000, D, T), width=W, stride=S)
+                    outs[mode] = p.run_host(data)
+                    info[mode] = (p.info.kernel_kind, p.info.tile_windows, p.info.threads)
+                except Q.QuadrsError as e:
+                    outs[mode] = str(e)
+            a, b = outs["0"], outs["1"]
+            ok = (isinstance(a, str) and isinstance(b, str)) or (
+                not isinstance(a, str) and not isinstance(b, str) and a.shape == b.shape and bits_equal(a, b))
+            desc = f"fmt={fmt} W={W} S={S} D={D} T={T} shift={shift} N={N} tune={tune} kinds={info}"
+            if log:
+                log(("ok  " if ok else "BAD ") + desc)
+            checked += 1
+            if not ok:
+                bad.append(desc)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return checked, bad
