@@ -48,10 +48,12 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-def fuzz_chain_shapes(Q, n_shapes, seed, log=None):
+def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
     """Random chain shapes through the plan-time compiler (QD_JIT=1; a quarter of them with a QD_TUNE tiling that
     exercises the register-tiled FIR / 16-byte LDS rows / wide workgroups) against the generic kernel (QD_JIT=0),
-    bit for bit.  Returns (checked, mismatching descriptions).  Q is the quadrs_amd package."""
+    bit for bit; with `oracle` (tests only) the first windows are also checked against the CPU oracle: bit-exact without
+    a shift stage, within 4 ulp of the window maximum with one.  Returns (checked, mismatching descriptions).
+    Q is the quadrs_amd package."""
     import os
     rng = np.random.default_rng(seed)
     checked, bad = 0, []
@@ -90,6 +92,21 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None):
             a, b = outs["0"], outs["1"]
             ok = (isinstance(a, str) and isinstance(b, str)) or (
                 not isinstance(a, str) and not isinstance(b, str) and a.shape == b.shape and bits_equal(a, b))
+            if ok and oracle is not None and not isinstance(a, str) and a.shape[0] > 0:
+                ch = oracle.Chain.from_bytes(data.tobytes(), fmt, 21_000_000)
+                if shift is not None:
+                    ch = ch.shift(shift)
+                ref, _ = ch.lowpass(1_000_000, D, T).spark_fft(W, S, max_windows=24)
+                got = a[:ref.shape[0]]
+                if shift is None:
+                    ok = bits_equal(ref, got)
+                else:
+                    # odd tap counts put a 0/0 in the middle of the reference's windowed sinc: NaN spectra, on both sides
+                    both_nan = np.isnan(ref) & np.isnan(got)
+                    with np.errstate(invalid="ignore"):
+                        scale = ulp_of(np.nanmax(np.where(np.isnan(ref), -np.inf, ref), axis=-1, keepdims=True)).astype(np.float64)
+                        close = np.abs(ref.astype(np.float64) - got.astype(np.float64)) <= 4.0 * scale
+                    ok = bool((close | both_nan).all())
             desc = f"fmt={fmt} W={W} S={S} D={D} T={T} shift={shift} N={N} tune={tune} kinds={info}"
             if log:
                 log(("ok  " if ok else "BAD ") + desc)
