@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 40 --warmup 3 --no-cpu-baseline "$@" > $out/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $out/write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/sq -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $out/sq.log 2>&1

@@ -11,6 +11,18 @@ ks = glob.glob(f"{out}/kt/*/*kernel_stats.csv")
 rows = list(csv.DictReader(open(ks[0])))
 chain = [r for r in rows if "k_chain" in r["Name"]]
 res["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in chain]
+# kernel_stats.csv averages every launch of the process, including bench.py's settle phase (isolated launches, each
+# followed by a synchronize, run a few % faster than back-to-back ones).  The timed region is the last 40 launches of
+# the kernel trace: their durations are what bench.py's roofline.kernel_ms must agree with.
+kt = glob.glob(f"{out}/kt/*/*kernel_trace.csv")
+if kt:
+    tr = [r for r in csv.DictReader(open(kt[0])) if "k_chain" in r["Kernel_Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    tr = tr[-40:]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
+    gap = [int(tr[i + 1]["Start_Timestamp"]) - int(tr[i]["End_Timestamp"]) for i in range(len(tr) - 1)]
+    res["timed_region"] = {"launches": len(tr), "kernel_avg_ns": sum(dur) / len(dur), "kernel_min_ns": min(dur),
+                           "gap_avg_ns": sum(gap) / max(1, len(gap)), "period_avg_ns": (sum(dur) + sum(gap)) / len(dur)}
 pmc = {}
 for d in ("fetch", "write", "sq", "sq2"):
     f = glob.glob(f"{out}/{d}/*/*counter_collection.csv")
