@@ -32,7 +32,7 @@ namespace qd {
 #define QD_STAMP_ROW(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_row[k] += t_ - st_prev; st_acc[0] += t_ - st_prev; st_prev = t_; } while (0)
 #define QD_STAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); } while (0)
 #define QD_STAMP_AT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 1024) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 1) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[129 + k_], st_row[k_]); if (w_ == 0) atomicAdd(&P.stamps[128], (unsigned long long)st_tiles); } } while (0)
+#define QD_STAMP_FLUSH() do { if (P.stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 1024) { unsigned w_ = threadIdx.x >> 6; for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&P.stamps[w_ * 8 + k_], st_acc[k_]); if (w_ == 1) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[129 + k_], st_row[k_]); if (w_ == 0) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&P.stamps[133 + k_], st_row[k_]); if (w_ == 0) atomicAdd(&P.stamps[128], (unsigned long long)st_tiles); } } while (0)
 #define QD_STAMP_TILE() do { ++st_tiles; } while (0)
 #else
 #define QD_STAMP_DECL
@@ -276,7 +276,13 @@ template <bool HAS_SHIFT>
 __device__ __forceinline__ double prefetch_rowtab(const ChainParams &P, const TileGeo &ng, uint32_t tid) {
     double v = 0.0;
     if constexpr (HAS_SHIFT) {
-        if (tid < ng.n_rows) v = *reinterpret_cast<const volatile double *>(&P.rowtab[ng.r0 - P.rowtab_row0 + tid].c);
+        // A plain load, unconditional (lanes past the last row re-touch it), index opaque so it stays inside the tile
+        // loop.  NOT volatile: hipcc turns a volatile load into `flat_load ... sc0 sc1` + `s_waitcnt vmcnt(0)`, i.e. a
+        // full drain of the next tile's prefetch at the top of every phase 1 on the wave that issued it (wave 0: +1.8k
+        // cycles per tile on cfg2, the other waves waiting for it at the barrier).
+        uint32_t r = tid < ng.n_rows ? tid : ng.n_rows - 1;
+        asm volatile("" : "+v"(r));
+        v = P.rowtab[ng.r0 - P.rowtab_row0 + r].c;
     }
     return v;
 }
@@ -901,8 +907,6 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 asm volatile("" :: "v"(v.x), "v"(v.y));      // force the wait for this row's data here
                 QD_STAMP_ROW(0);
 #endif
-                pf[i] = fetch_row<FMT, NT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
-                QD_STAMP_ROW(1);
                 if ((uint32_t)i < tg.n_rows) {
                     const RowBase rb = rb_next;
 #ifdef QD_STAMP
@@ -915,6 +919,14 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                     process_row_any<FMT, NT, NCO>(P, geo, tg, i, tid, v, rb, lr, lane_pad, lut, raw);
                     QD_STAMP_ROW(3);
                 }
+                // Refill slot i only now, into the registers row i just vacated.  Issued before the row is consumed
+                // the new load needs different registers, the slots rotate by one per tile, and hipcc squares that at the
+                // loop's back edge with register copies behind an s_waitcnt vmcnt(0) — a full drain of the next tile's
+                // prefetch at the end of every tile.
+                __builtin_amdgcn_sched_barrier(0);
+                pf[i] = fetch_row<FMT, NT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
+                QD_STAMP_ROW(1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             for (uint32_t r = 0; r < tg.n_rows; r += RCH) {

@@ -541,6 +541,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
             fprintf(stderr, "  total=%.0f", tot);
         }
         fprintf(stderr, "\n   wave1 phase-1 split per tile: wait_data=%.0f issue_prefetch=%.0f wait_rowbase=%.0f process=%.0f\n", h[129] / tiles, h[130] / tiles, h[131] / tiles, h[132] / tiles);
+        fprintf(stderr, "   wave0 phase-1 split per tile: wait_data=%.0f issue_prefetch=%.0f wait_rowbase=%.0f process=%.0f\n", h[133] / tiles, h[134] / tiles, h[135] / tiles, h[136] / tiles);
     }
 #endif
     return QD_OK;

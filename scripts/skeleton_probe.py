@@ -20,5 +20,5 @@ def run(shift, skip, jit):
     torch.cuda.synchronize()
     ms = e[0].elapsed_time(e[40]) / 40
     print(f"shift={shift} skip={skip} jit={jit} kind={p.info.kernel_kind} G={p.info.tile_windows}: {ms:.4f} ms  {N*8.25/ms/1e6:.0f} GB/s", flush=True)
-for skip in (0, 512, 0, 512):
+for skip in (0, 14, 14 + 16, 14 + 32, 14 + 16 + 32, 15 + 16 + 32, 16, 0):
     run(280000, skip, "1")
