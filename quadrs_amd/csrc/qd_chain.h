@@ -76,6 +76,7 @@ struct ChainParams {
     float root2;
     float2 tw16_1, tw16_2, tw16_3;
     uint32_t epi;              // qd_epilogue
+    float gstep;               // glyph epilogue: (rmax - rmin) / 7.0f, computed on the host (see glyph_code)
     uint32_t dbg;              // timing-only ablation bits (QD_DEBUG_SKIP; 1 NCO, 2 FIR, 4 FFT, 8 hypot, 16 output store, 32 LDS staging); 0 in every real run
     unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
     const uint64_t *row_offsets; // take_fft (src/ffts.rs:59-60): window w starts at row_offsets[w] (generic kernels, G = 1)
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 asm volatile("" : "+v"(oo));
                 if (P.dbg & 16) { asm volatile("" :: "v"(nm)); continue; }      // timing-only ablation: no output store
                 if (P.epi == 0) outf[oo] = nm;
-                else outb[oo] = glyph_code(nm, P.rmin, P.rmax);
+                else outb[oo] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
             }
         }
         rt_touch += rt_pf;       // first use of the touch loads: a whole tile after they were issued

@@ -61,8 +61,10 @@ __device__ __forceinline__ float unpack_cs16(uint32_t h) {
 
 // ---------------------------------------------------------------- glyph (src/fft.rs:45,54-60)
 
-__device__ __forceinline__ uint8_t glyph_code(float norm, float mn, float mx) {
-    float distinction = (mx - mn) / 7.0f;
+// `distinction` = (mx - mn) / 7.0f (src/fft.rs:45) is computed once on the host (same correctly rounded f32 division)
+// and arrives as a kernel argument: left to hipcc it is hoisted out of the tile loop into a VGPR that gets spilled, and
+// the reload in the epilogue carries an s_waitcnt vmcnt(0) — a full drain of the next tile's prefetch.
+__device__ __forceinline__ uint8_t glyph_code(float norm, float mn, float mx, float distinction) {
     if (norm < mn) return 0;
     if (norm >= mx) return 8;
     float f = (norm - mn) / distinction;
