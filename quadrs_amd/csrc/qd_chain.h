@@ -1216,7 +1216,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 float first = 0.f, second = 0.f;
                 for (uint32_t k = 0; k < W / 2; ++k) first = first + p[k];
                 for (uint32_t k = W / 2; k < W; ++k) second = second + p[k];
-                reinterpret_cast<uint8_t *>(P.out)[wrel + tid] = first < second ? 0 : 1;
+                uint32_t tt = tid;
+                asm volatile("" : "+v"(tt));       // opaque lane offset: no hoisted (and spilled) per-lane output pointer, see below
+                reinterpret_cast<uint8_t *>(P.out)[wrel + tt] = first < second ? 0 : 1;
             }
         } else {
             float *outf = reinterpret_cast<float *>(P.out) + (wrel << logW);     // uniform base

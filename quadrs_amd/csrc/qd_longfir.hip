@@ -22,9 +22,10 @@ namespace qd {
 
 static const FixedEntry kLongFir[] = {
     // README.md:90-94 / configs[2]  "lowpass -power 200 -decimate 32 200000 | sparkfft -width 64 -stride 16"
-    // cf32 input (the README's own FSK example file): 2048-sample rows, 9 per tile
-    QD_FIXED_NT(0, 1, 64, 16, 32, 400, 27, 9, true, 4, 1024, 8, 1, 2, "fsk5"),
-    QD_FIXED_NT(0, 2, 64, 16, 32, 400, 27, 9, true, 4, 1024, 8, 1, 2, "fsk5"),
+    // cf32 input (the README's own FSK example file): 2048-sample rows, 9 per tile, prefetched 4 rows at a time (a whole
+    // tile in registers spills at 128 VGPRs)
+    QD_FIXED_NT(0, 1, 64, 16, 32, 400, 27, 4, false, 4, 1024, 8, 1, 2, "fsk5"),
+    QD_FIXED_NT(0, 2, 64, 16, 32, 400, 27, 4, false, 4, 1024, 8, 1, 2, "fsk5"),
 #ifndef QD_DEV_FAST
     // cs8 input (HackRF): 4096-sample rows, 5 per tile, whole-tile register prefetch
     QD_FIXED_NT(1, 1, 64, 16, 32, 400, 27, 5, true, 4, 1024, 8, 1, 2, "cfg3"),
