@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -278,15 +280,49 @@ std::string csrc_dir() {
     return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/csrc";
 }
 
-// returns nullptr (and leaves a message in *why) when specialisation is not possible
-hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
+// ---- on-disk cache of plan-time builds: a compile costs ~0.3-1 s, which a single pass over anything smaller than tens
+// of GiB never repays; a cached code object loads in ~1 ms.  Directory: $QD_JIT_CACHE ("0" / "off" disables), else
+// $XDG_CACHE_HOME/quadrs_hip, else $HOME/.cache/quadrs_hip.  File name: FNV-1a of (kernel name, options, the two kernel
+// headers' contents); file = "QDJIT1\n<lowered name>\n" + code object.  Every failure just means "not cached".
+uint64_t fnv1a(const void *data, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+bool read_file(const std::string &path, std::vector<char> *out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return false; }
+    out->resize((size_t)n);
+    const bool ok = n == 0 || fread(out->data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+std::string jit_cache_dir() {
+    std::string d;
+    if (const char *e = getenv("QD_JIT_CACHE")) {
+        if (!*e || !strcmp(e, "0") || !strcmp(e, "off")) return "";
+        d = e;
+    } else if (const char *x = getenv("XDG_CACHE_HOME")) { if (*x) d = std::string(x) + "/quadrs_hip"; }
+    if (d.empty()) { const char *h = getenv("HOME"); if (!h || !*h) return ""; d = std::string(h) + "/.cache/quadrs_hip"; }
+    for (size_t i = 1; i <= d.size(); ++i)                       // mkdir -p; errors surface as "cannot write" later
+        if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0755);
+    return d;
+}
+
+// returns nullptr (and leaves a message in *why) when specialisation is not possible; with may_compile false only the
+// in-process and on-disk caches are consulted
+hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compile = true) {
     std::lock_guard<std::mutex> lock(g_jit_mu);
     auto it = g_jit_cache.find(k);
     if (it != g_jit_cache.end()) return it->second;
     const std::string dir = csrc_dir();
-    FILE *probe = fopen((dir + "/qd_chain.h").c_str(), "r");
-    if (!probe) { *why = "kernel headers not found next to the library (" + dir + ")"; return nullptr; }
-    fclose(probe);
+    std::vector<char> hdr1, hdr2;
+    if (!read_file(dir + "/qd_chain.h", &hdr1) || !read_file(dir + "/qd_device.h", &hdr2)) {
+        *why = "kernel headers not found next to the library (" + dir + ")";
+        return nullptr;
+    }
     char name[512];
     snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
              k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
@@ -311,6 +347,32 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
         }
         for (const std::string &x : extra) optv.push_back(x.c_str());
     }
+    // cache lookup (the -I path is excluded from the key: the headers' contents are in it)
+    std::string cache_file;
+    {
+        uint64_t h = fnv1a(name, strlen(name));
+        for (const char *o : optv) if (o != inc.c_str()) h = fnv1a(o, strlen(o) + 1, h);
+        h = fnv1a(hdr1.data(), hdr1.size(), h);
+        h = fnv1a(hdr2.data(), hdr2.size(), h);
+        const std::string cdir = getenv("QD_JIT_DUMP") ? std::string() : jit_cache_dir();
+        if (!cdir.empty()) { char fn[64]; snprintf(fn, sizeof fn, "/%016llx.co", (unsigned long long)h); cache_file = cdir + fn; }
+    }
+    if (!cache_file.empty()) {
+        std::vector<char> blob;
+        if (read_file(cache_file, &blob) && blob.size() > 8 && !memcmp(blob.data(), "QDJIT1\n", 7)) {
+            const char *nm = blob.data() + 7, *end = static_cast<const char *>(memchr(nm, '\n', blob.size() - 7));
+            if (end) {
+                const std::string lowered(nm, end);
+                hipModule_t mod; hipFunction_t fn = nullptr;
+                if (hipModuleLoadData(&mod, end + 1) == hipSuccess && hipModuleGetFunction(&fn, mod, lowered.c_str()) == hipSuccess) {
+                    hiprtcDestroyProgram(&prog);
+                    g_jit_cache[k] = fn;
+                    return fn;
+                }
+            }
+        }
+    }
+    if (!may_compile) { *why = "not cached and the stream is too small to repay a plan-time build"; hiprtcDestroyProgram(&prog); return nullptr; }
     hiprtcResult r = hiprtcCompileProgram(prog, (int)optv.size(), optv.data());
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
@@ -332,6 +394,16 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why) {
         *why = "hipModuleLoadData / GetFunction failed";
         hiprtcDestroyProgram(&prog);
         return nullptr;
+    }
+    if (!cache_file.empty()) {                               // publish atomically: write aside, then rename
+        char tmpn[32]; snprintf(tmpn, sizeof tmpn, ".tmp%d", (int)getpid());
+        const std::string tmp = cache_file + tmpn;
+        if (FILE *f = fopen(tmp.c_str(), "wb")) {
+            bool ok = fwrite("QDJIT1\n", 1, 7, f) == 7 && fputs(lowered, f) >= 0 && fputc('\n', f) != EOF &&
+                      fwrite(code.data(), 1, code.size(), f) == code.size();
+            ok = fclose(f) == 0 && ok;
+            if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
+        }
     }
     hiprtcDestroyProgram(&prog);
     g_jit_cache[k] = fn;
@@ -652,21 +724,34 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     const char *jenv = getenv("QD_JIT");
     const int jmode = jenv ? atoi(jenv) : -1;                       // -1 auto, 0 off, 1 force
     const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
-    const bool jit_ok = !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS &&
-                        (jmode == 1 || (jmode != 0 && in_bytes >= (16ull << 20)));
+    const bool jit_ok = !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS && jmode != 0;
+    // a cached build is always used; a NEW build only when forced or when the stream is at least 1 GiB
+    const bool may_compile = jmode == 1 || tuned || in_bytes >= (1ull << 30);
+    auto make_key = [&](uint32_t g, int nt, int lb, int noslp, uint32_t padv) {
+        const uint64_t ROW = (uint64_t)nt * spl_of(d.format);
+        const uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
+        // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
+        const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
+        return JitKey{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, lb, nt,
+                      p->W, p->S, p->D, p->T, g, tune[3], tune[2], noslp, padv};
+    };
     // FIR-dominated shapes (>= 8 taps per input sample): a tile's FIR phase is latency-bound — one wave walks
     // all T taps however few outputs the tile has — so take the largest tile with <= 512 FIR outputs that LDS
     // allows, 512 threads, a 256-VGPR budget and scalar accumulate chains (measured 1.3-2.9x over the small-tile
     // default on six such shapes, scripts/policy_probe.py)
-    const bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D;
+    bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D;
     int jit_lb = 4, jit_noslp = 0;
     uint32_t pad = 1;              // LDS pad elements per row the main kernel is built with (FixedGeo PAD_)
     if (heavy) {
         auto outs = [&](uint32_t g) { return p->S < p->W ? (uint64_t)(g - 1) * p->S + p->W : (uint64_t)g * p->W; };
-        pad = 2;                   // 16-byte aligned LDS rows: ds_read_b128 sample pairs in the tap loop (FixedGeo::kPad)
-        while (G < 64 && outs(G + 1) <= 512 && lds_for(G + 1, p->W, p->S, p->D, T_lds, nullptr, pad) <= kLdsMax) ++G;
-        if (p->n_windows && G > p->n_windows) G = (uint32_t)p->n_windows;
-        p->nt = 512; jit_lb = 2; jit_noslp = 1;
+        uint32_t gh = 1;           // 16-byte aligned LDS rows (pad 2): ds_read_b128 sample pairs in the tap loop (FixedGeo::kPad)
+        while (gh < 64 && outs(gh + 1) <= 512 && lds_for(gh + 1, p->W, p->S, p->D, T_lds, nullptr, 2) <= kLdsMax) ++gh;
+        if (p->n_windows && gh > p->n_windows) gh = (uint32_t)p->n_windows;
+        p->jit_fn = jit_chain_kernel(make_key(gh, 512, 2, 1, 2), &p->jit_note, may_compile);
+        heavy = p->jit_fn != nullptr;                  // else: the default tiling below, on whatever kernel is available
+        if (heavy) { G = gh; pad = 2; p->nt = 512; jit_lb = 2; jit_noslp = 1; }
+    }
+    if (heavy) {
     } else if (tuned) {
         G = tune[0];
         p->nt = (int)tune[1];
@@ -692,15 +777,9 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (!p->fn || !p->fn_unaligned) return fail(QD_ERR_UNSUPPORTED, "no kernel built for this format (QD_DEV_FAST build?)");
     {
         // plan-time specialisation for shapes without a built-in FixedGeo kernel
-        const bool want = tuned || (!p->fixed && jit_ok);
+        const bool want = !heavy && (tuned || (!p->fixed && jit_ok));
         if (want) {
-            const uint64_t ROW = (uint64_t)p->nt * spl_of(d.format);
-            const uint64_t tile_raw = (uint64_t)(G - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
-            // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
-            const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
-            JitKey k{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, jit_lb, p->nt,
-                     p->W, p->S, p->D, p->T, G, tune[3], tune[2], jit_noslp, pad};
-            p->jit_fn = jit_chain_kernel(k, &p->jit_note);
+            p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad), &p->jit_note, may_compile);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "QD_TUNE build failed: %s", p->jit_note.c_str());
         }
     }

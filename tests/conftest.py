@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # plan-time builds made by the tests go to a throw-away cache, not to ~/.cache/quadrs_hip
+    if "QD_JIT_CACHE" not in os.environ:
+        import atexit, shutil, tempfile
+        d = tempfile.mkdtemp(prefix="quadrs_hip_jit_")
+        os.environ["QD_JIT_CACHE"] = d
+        atexit.register(shutil.rmtree, d, True)
 
 
 @pytest.fixture(scope="session")

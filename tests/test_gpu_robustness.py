@@ -180,3 +180,39 @@ def test_random_shapes_specialised_equals_generic(engine, oracle):
     from util import fuzz_chain_shapes
     checked, bad = fuzz_chain_shapes(Q, 36, 20260101, oracle=oracle)
     assert checked >= 25 and not bad, bad
+
+
+def test_plan_time_builds_are_cached_on_disk(tmp_path):
+    """A plan-time build lands in $QD_JIT_CACHE; a later process whose stream is far too small to justify a compile
+    (auto mode) still gets the specialised kernel from the cache, and the same bits."""
+    import subprocess, sys, textwrap
+    if os.environ.get("QD_NO_FIXED"):
+        pytest.skip("QD_NO_FIXED=1 runs the generic kernels only")
+    code = textwrap.dedent("""
+        import sys, zlib, numpy as np
+        sys.path.insert(0, %r)
+        import quadrs_amd as Q
+        N = 200_000
+        x = (np.random.default_rng(4).standard_normal((N, 2)) * 0.05).astype(np.float32)
+        p = Q.Plan(0, 21_000_000, N, shift_hz=123_456, lowpass=(700_000, 12, 56), width=32, stride=24)
+        out = p.run_host(x.tobytes())
+        print(p.info.kernel_kind, zlib.crc32(out.tobytes()))
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, QD_JIT_CACHE=str(tmp_path))
+    env.pop("QD_TUNE", None)
+    def run(jit):
+        e = dict(env)
+        if jit is None:
+            e.pop("QD_JIT", None)
+        else:
+            e["QD_JIT"] = jit
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        kind, crc = r.stdout.split()[-2:]
+        return int(kind), crc
+    assert run(None) == (0, run("0")[1])                 # nothing cached, small stream: generic kernel
+    assert not list(tmp_path.glob("*.co"))
+    kind, crc = run("1")                                 # forced build -> cache file
+    assert kind == 2 and len(list(tmp_path.glob("*.co"))) == 1
+    assert run(None) == (2, crc)                         # auto mode now finds it
+    assert run("0")[1] == crc                            # and the generic kernel agrees bit for bit
