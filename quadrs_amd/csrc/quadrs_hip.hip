@@ -974,7 +974,8 @@ int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, ui
     const uint64_t obw = out_bytes_per_window(p) / subs;      // per kernel window (a sub-block for QD_EPI_CF32_BLOCKS)
     first_window *= subs; n_windows *= subs;                  // from here on: kernel-window units
     const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
-    const uint64_t target_bytes = 64ull << 20;
+    uint64_t target_bytes = 64ull << 20;
+    if (const char *e = getenv("QD_CHUNK_MB")) { int v = atoi(e); if (v >= 1 && v <= 4096) target_bytes = (uint64_t)v << 20; }   // tuning knob
     uint64_t cw = target_bytes / (step * bps ? step * bps : 1);
     if (cw < p->geo.G) cw = p->geo.G;
     cw = (cw / p->geo.G) * p->geo.G;
