@@ -163,6 +163,14 @@ int qd_plan_run(qd_plan *plan, const void *src, int src_mem, uint64_t src_first,
 int qd_plan_set_timing(qd_plan *plan, int enabled);
 int qd_plan_last_kernel_ms(qd_plan *plan, float *ms);
 
+/* Device buffers for callers that keep a stream resident in HBM — e.g. `gen ... | lowpass | sparkfft`
+ * (src/gen.rs + BASELINE configs[3]): the samples are generated on the device by qd_gen and never cross PCIe.
+ * Plain hipMalloc / hipFree / hipMemcpy behind the ABI so that a host without a HIP toolchain can use
+ * qd_plan_run's device path.  qd_device_copy is synchronous; *_mem are qd_mem values. */
+int qd_device_alloc(size_t bytes, void **ptr);
+int qd_device_free(void *ptr);
+int qd_device_copy(void *dst, int dst_mem, const void *src, int src_mem, size_t bytes);
+
 /* Fill a device (or host) buffer with Gen's samples, src/gen.rs:35-47 (device-side source
  * for `gen ... sparkfft` chains; A9). */
 int qd_gen(const int64_t *cos_hz, size_t n_cos, uint64_t sample_rate, uint64_t first, size_t n,

@@ -17,6 +17,7 @@ SYMBOLS = [
     "qd_shift_ratio", "qd_shift", "qd_lowpass_design", "qd_lowpass_block", "qd_fft_norm_batch",
     "qd_plan_create", "qd_plan_destroy", "qd_plan_get_info", "qd_plan_get_taps", "qd_plan_src_range",
     "qd_plan_run", "qd_plan_set_timing", "qd_plan_last_kernel_ms", "qd_gen", "qd_take_fft",
+    "qd_device_alloc", "qd_device_free", "qd_device_copy",
 ]
 
 
@@ -88,6 +89,9 @@ def lib():
             "qd_plan_set_timing": (i32, [vp, i32]),
             "qd_plan_last_kernel_ms": (i32, [vp, C.POINTER(f32)]),
             "qd_gen": (i32, [vp, sz, u64, u64, sz, vp, i32]),
+            "qd_device_alloc": (i32, [sz, C.POINTER(C.c_void_p)]),
+            "qd_device_free": (i32, [vp]),
+            "qd_device_copy": (i32, [vp, i32, vp, i32, sz]),
             "qd_take_fft": (i32, [vp, u64, sz, u64, i32, u64, u64, sz, i32, sz, vp, i32]),
         }
         for name, (res, args) in sig.items():

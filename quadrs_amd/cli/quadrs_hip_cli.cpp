@@ -356,13 +356,23 @@ std::vector<uint8_t> slurp(const std::string &fn) {
     return d;
 }
 
-// sparkfft / bucket through ONE fused plan over the whole file
+// device buffer that frees itself (the `gen` source of a fused chain lives in HBM)
+struct DeviceBuf {
+    void *p = nullptr;
+    ~DeviceBuf() { if (p) qd_device_free(p); }
+};
+
+// sparkfft / bucket through ONE fused plan over the whole file — or over a `gen` stream that is produced on the device
+// (src/gen.rs:30-47) and never crosses PCIe: only the glyph codes / digits come back
 void run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
-    std::vector<uint8_t> data = slurp(cs.src->filename);
+    const bool from_gen = cs.src->kind == OP_GEN;
+    std::vector<uint8_t> data;
+    if (!from_gen) data = slurp(cs.src->filename);
     qd_chain_desc d{};
     d.struct_size = sizeof d;
-    d.format = cs.src->format; d.sample_rate = cs.src->sample_rate;
-    d.n_samples = data.size() / qd_pair_bytes(cs.src->format);
+    d.format = from_gen ? QD_FMT_CF32 : cs.src->format; d.sample_rate = cs.src->sample_rate;
+    d.n_samples = from_gen ? (uint64_t)(cs.src->seconds * (double)cs.src->sample_rate)          // Gen::len, src/gen.rs:32
+                           : data.size() / qd_pair_bytes(cs.src->format);
     if (cs.shift) { d.has_shift = 1; d.shift_hz = cs.shift->shift; }
     if (cs.lowpass) { d.has_lowpass = 1; d.lowpass_hz = cs.lowpass->lp_freq; d.decimate = cs.lowpass->decimate; d.taps = cs.lowpass->size; }
     d.width = sink.width; d.stride = sink.stride;
@@ -374,8 +384,22 @@ void run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
     qd_plan_info info;
     qd_check(qd_plan_get_info(plan, &info), "plan info");
     std::vector<uint8_t> out(info.n_windows * info.out_bytes_per_window + 1);
-    if (info.n_windows)
+    if (info.n_windows && !from_gen)
         qd_check(qd_plan_run(plan, data.data(), QD_MEM_HOST, 0, d.n_samples, 0, info.n_windows, out.data(), QD_MEM_HOST, nullptr), "run");
+    if (info.n_windows && from_gen) {
+        DeviceBuf src, dst;
+        const size_t ob = (size_t)(info.n_windows * info.out_bytes_per_window);
+        qd_check(qd_device_alloc((size_t)d.n_samples * 8, &src.p), "device buffer for gen");
+        qd_check(qd_device_alloc(ob, &dst.p), "device buffer for the sink");
+        const uint64_t piece = 1ull << 28;                                   // Gen::read_at in pieces: bounded kernel launches
+        for (uint64_t a = 0; a < d.n_samples; a += piece) {
+            const uint64_t n = d.n_samples - a < piece ? d.n_samples - a : piece;
+            qd_check(qd_gen(cs.src->cos.data(), cs.src->cos.size(), cs.src->sample_rate, a, (size_t)n,
+                            static_cast<qd_c32 *>(src.p) + a, QD_MEM_DEVICE), "gen");
+        }
+        qd_check(qd_plan_run(plan, src.p, QD_MEM_DEVICE, 0, d.n_samples, 0, info.n_windows, dst.p, QD_MEM_DEVICE, nullptr), "run");
+        qd_check(qd_device_copy(out.data(), QD_MEM_HOST, dst.p, QD_MEM_DEVICE, ob), "copy back");   // synchronises with the launch
+    }
     qd_plan_destroy(plan);
     if (sink.kind == OP_SPARKFFT) {
         // header already printed; rows only
@@ -468,7 +492,7 @@ void do_write(const Samples &s, bool overwrite, const std::string &prefix, const
     if (fd < 0) bail(std::string(strerror(errno)) + " (os error " + std::to_string(errno) + ")");
     uint64_t off = 0, len;
     try { len = s.len(); } catch (...) { close(fd); throw; }
-    if (cs && cs->fusable && cs->lowpass && !getenv("QUADRS_HIP_NO_FUSE")) {
+    if (cs && cs->fusable && cs->src->kind == OP_FROM && cs->lowpass && !getenv("QUADRS_HIP_NO_FUSE")) {
         std::vector<uint8_t> data = slurp(cs->src->filename);
         qd_chain_desc d{};
         d.struct_size = sizeof d;
@@ -540,7 +564,7 @@ int main(int argc, char **argv) {
                 break;
             case OP_GEN:
                 samples.reset(new Gen(op.cos, op.sample_rate, op.seconds));
-                cs = ChainSpec{}; chain_clean = false;
+                cs = ChainSpec{}; cs.src = &op; cs.fusable = true; chain_clean = true;
                 break;
             case OP_SHIFT:
                 if (!samples) bail("shift requires an input");

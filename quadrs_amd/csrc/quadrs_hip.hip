@@ -1198,6 +1198,30 @@ int qd_take_fft(const qd_c32 *in, uint64_t in_first, size_t n_in, uint64_t sampl
     return cleanup(rc);
 }
 
+int qd_device_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return fail(QD_ERR_INVALID, "NULL argument");
+    *ptr = nullptr;
+    if (bytes == 0) return QD_OK;
+    HIPCHK(hipMalloc(ptr, bytes));
+    return QD_OK;
+}
+
+int qd_device_free(void *ptr) {
+    if (ptr) HIPCHK(hipFree(ptr));
+    return QD_OK;
+}
+
+int qd_device_copy(void *dst, int dst_mem, const void *src, int src_mem, size_t bytes) {
+    if (bytes == 0) return QD_OK;
+    if (!dst || !src) return fail(QD_ERR_INVALID, "NULL buffer");
+    if ((dst_mem != QD_MEM_HOST && dst_mem != QD_MEM_DEVICE) || (src_mem != QD_MEM_HOST && src_mem != QD_MEM_DEVICE))
+        return fail(QD_ERR_INVALID, "unknown memory kind");
+    const hipMemcpyKind kind = dst_mem == QD_MEM_DEVICE ? (src_mem == QD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
+                                                        : (src_mem == QD_MEM_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+    HIPCHK(hipMemcpy(dst, src, bytes, kind));
+    return QD_OK;
+}
+
 int qd_gen(const int64_t *cos_hz, size_t n_cos, uint64_t sample_rate, uint64_t first, size_t n, qd_c32 *out, int mem) {
     if (!cos_hz || n_cos == 0) return fail(QD_ERR_INVALID, "cos cannot be empty (src/gen.rs:18)");
     if (sample_rate == 0) return fail(QD_ERR_INVALID, "sample rate may not be zero (src/gen.rs:19)");

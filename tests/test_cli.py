@@ -122,3 +122,21 @@ def test_gen_chain(cli, oracle):
     assert r.returncode == 0, r.stderr
     want = oracle.Chain.gen([1000, -3000], 48000, 0.01).spark_text(16, 16, (0.5, 20.0))
     assert r.stdout == want
+
+
+@pytest.mark.gpu
+def test_gen_source_runs_fused_on_the_device(cli, oracle):
+    """`gen ... | shift | lowpass | sparkfft` and `... | bucket`: the tones are generated in HBM (qd_gen on a device buffer),
+    the chain runs as one plan on them and only glyphs / digits come back — same text as the block-iterator path and as
+    the oracle."""
+    chain = ["gen", "-cos", "1000", "-cos", "-3k", "-cos", "7500", "-len", "0.25", "48k",
+             "shift", "-1200", "lowpass", "-power", "12", "-decimate", "4", "4000"]
+    for sink in (["sparkfft", "-width", "16", "-stride", "8", "-range", "0.02:3"], ["bucket", "-width", "32", "-by", "freq", "2"]):
+        fused = run(cli, *chain, *sink)
+        slow = run(cli, *chain, *sink, env={"QUADRS_HIP_NO_FUSE": "1"})
+        assert fused.returncode == 0 and slow.returncode == 0, (fused.stderr, slow.stderr)
+        assert fused.stdout == slow.stdout and len(fused.stdout) > 50
+    ch = oracle.Chain.gen([1000, -3000, 7500], 48000, 0.25).shift(-1200).lowpass(4000, 4, 24)
+    want = ch.spark_text(16, 8, (0.02, 3.0))
+    got = run(cli, *chain, "sparkfft", "-width", "16", "-stride", "8", "-range", "0.02:3").stdout
+    assert got.decode() == want if isinstance(want, str) else got == want
