@@ -216,3 +216,37 @@ def test_plan_time_builds_are_cached_on_disk(tmp_path):
     assert kind == 2 and len(list(tmp_path.glob("*.co"))) == 1
     assert run(None) == (2, crc)                         # auto mode now finds it
     assert run("0")[1] == crc                            # and the generic kernel agrees bit for bit
+
+
+def test_device_buffers_through_the_abi_only(engine):
+    """A host without torch or a HIP toolchain: qd_device_alloc / qd_gen into HBM / qd_plan_run device -> device /
+    qd_device_copy back — equal, bit for bit, to the host-buffer path on the same generated stream; plus the argument
+    checks of the three device calls."""
+    from quadrs_amd import _ffi
+    L, check = _ffi.lib(), _ffi.check
+    sr, n = 2_000_000, 300_000
+    tones = np.array([150_000, -420_000, 731_000], dtype=np.int64)
+    host = engine.gen(tones, sr, 0, n)                                   # same kernel, host destination
+    p = engine.Plan(0, sr, n, shift_hz=-50_000, lowpass=(200_000, 8, 64), width=64, stride=32)
+    want = p.run_host(host.tobytes())
+    src, dst = C.c_void_p(), C.c_void_p()
+    ob = p.n_windows * 64 * 4
+    check(L.qd_device_alloc(n * 8, C.byref(src)))
+    check(L.qd_device_alloc(ob, C.byref(dst)))
+    try:
+        check(L.qd_gen(tones.ctypes.data_as(C.c_void_p), tones.size, sr, 0, n, src, _ffi.MEM_DEVICE))
+        check(L.qd_plan_run(p._h, src, _ffi.MEM_DEVICE, 0, n, 0, p.n_windows, dst, _ffi.MEM_DEVICE, None))
+        got = np.zeros((p.n_windows, 64), dtype=np.float32)
+        check(L.qd_device_copy(got.ctypes.data_as(C.c_void_p), _ffi.MEM_HOST, dst, _ffi.MEM_DEVICE, ob))   # synchronises
+        assert bits_equal(got, want)
+        back = np.zeros((n, 2), dtype=np.float32)
+        check(L.qd_device_copy(back.ctypes.data_as(C.c_void_p), _ffi.MEM_HOST, src, _ffi.MEM_DEVICE, n * 8))
+        assert bits_equal(back, host)
+        assert L.qd_device_copy(None, _ffi.MEM_HOST, src, _ffi.MEM_DEVICE, 8) == 1            # QD_ERR_INVALID
+        assert L.qd_device_copy(back.ctypes.data_as(C.c_void_p), 7, src, _ffi.MEM_DEVICE, 8) == 1
+        assert L.qd_device_alloc(16, None) == 1
+        z = C.c_void_p(1)
+        assert L.qd_device_alloc(0, C.byref(z)) == 0 and not z.value                          # empty buffer: NULL, no error
+    finally:
+        L.qd_device_free(src); L.qd_device_free(dst)
+    assert L.qd_device_free(None) == 0
