@@ -1,7 +1,8 @@
 """Copies the summaries scripts/profile_round.sh left under gpurun_out/profiles_out into profiles/<round>/ and
 rebuilds profiles/traffic_latest.json (what bench.py reports as roofline.traffic, per workload).
-cs8/cu8/cs16 workloads load 8 B per lane: FETCH_SIZE is uncalibrated for that width on gfx950
-(MI355X_MICROARCH.md, HBM section), so their traffic stays null."""
+The factor 2 on FETCH_SIZE (MI355X_MICROARCH.md, HBM section, stated there for 16 B/lane) was calibrated here for the widths this
+kernel uses: scripts/ubench_fetch.hip streams a known byte count with 16, 8 and 4 bytes per lane and FETCH_SIZE*1024 comes out
+at exactly 0.5000 of the bytes for all three (scripts/fetch_cal.py), so the cs8 workload's traffic is reported too."""
 import json, os, shutil, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = "gpurun_out/profiles_out", f"profiles/{rnd}"
@@ -16,7 +17,7 @@ for f in sorted(os.listdir(src)):
     if f.endswith(".json"):
         d = json.load(open(os.path.join(src, f)))
         wl = d["workload"]
-        calibrated = wl in ("cfg2", "cfg3p", "cfg4")          # cf32 sources: 16 B per lane
+        calibrated = True                                     # 16 and 8 B per lane both calibrated (see the docstring)
         traffic["workloads"][wl] = {
             "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch") if calibrated else None,
             "kernel_avg_ns": (d.get("timed_region") or {}).get("kernel_avg_ns") or (float(d["kernel_stats"][0]["AverageNs"]) if d["kernel_stats"] else None),
