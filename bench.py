@@ -2,47 +2,82 @@
 """bench.py — Msamples/s through the fused shift -> FIR -> FFT chain on MI355X.
 
 One "step" = one pass of the hot path over this rank's slab of a synthetic IQ stream that is
-already resident in HBM.  Default workload = BASELINE.json configs[1] ("cfg2"):
-1 GiB cf32 @21 Msps per GPU, shift 280000 -> lowpass -power 20 -decimate 16 2000000 ->
-sparkfft -width 128.  With --gpus N the stream is N slabs (weak scaling), sharded by contiguous
-window ranges with a (W-S)*D+T-sample halo fetched once from the next rank over RCCL.
+already resident in HBM.  Default workload = the configuration BASELINE.json's north_star target is
+quoted on ("cfg3p"): a 16 GiB cf32 stream per GPU, shift -> 200-tap FIR decimate 32 -> 128-pt FFT.
+The other BASELINE configs (cfg2 / cfg3 / cfg4) are `--workload` choices and, in the default
+one-GPU run, are also timed briefly and reported under "others".
+
+With --gpus N the stream is N slabs (weak scaling), sharded by contiguous window ranges with a
+(W-S)*D+T-sample halo fetched once from the next rank over RCCL.  `python bench.py --gpus N` with no
+launcher starts its own N rank processes (before anything touches the GPU); under
+`torch.distributed.run` it is one rank of the job.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     — algorithmic HBM bytes per launch / mean kernel time from HIP events recorded on
-                 the launch stream (torch's current stream is handed to the C ABI);
+  roofline     — both roofs of the chain kernel: HBM (algorithmic bytes per launch / mean kernel time
+                 from HIP events on the launch stream, peak 8 TB/s) and VALU (the chain's arithmetic at
+                 the issue rates measured by scripts/ubench_valu.hip); "bound" names the lower one;
   cpu_baseline — the CPU oracle in reference-literal mode (single thread, the reference CLI is
                  single-threaded) on a bounded sample of the same workload.
 """
 import argparse
-import ctypes
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: fmt, samples per GPU, sample_rate, shift, (fc, decimate, taps), width, stride
+    "cfg3p": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=280000, lp=(200_000, 32, 200), W=128, S=128,
+                  desc="16 GiB cf32: shift 280000 -> 200-tap FIR (lowpass -power 100) decimate 32 -> sparkfft -width 128 (north_star target chain)"),
     "cfg2": dict(fmt=0, n=1 << 27, sr=21_000_000, shift=280000, lp=(2_000_000, 16, 40), W=128, S=128,
                  desc="1 GiB cf32 @21Msps: shift 280000 -> lowpass -power 20 -decimate 16 2000000 -> sparkfft -width 128"),
-    "cfg3p": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=280000, lp=(200_000, 32, 200), W=128, S=128,
-                  desc="16 GiB cf32: shift -> 200-tap FIR decimate 32 -> 128-pt FFT (north_star target sentence)"),
     "cfg3": dict(fmt=1, n=1 << 33, sr=21_000_000, shift=280000, lp=(200_000, 32, 400), W=64, S=16,
                  desc="16 GiB cs8: unpack -> shift -> lowpass -power 200 -decimate 32 200000 -> sparkfft -width 64 -stride 16"),
     "cfg4": dict(fmt=0, n=1 << 32, sr=100_000_000, shift=None, lp=(5_000_000, 8, 512), W=1024, S=1024,
                  desc="gen 64 cosines @100 Msps, 32 GiB cf32: 512-tap FIR decimate 8 -> 1024-pt FFT"),
 }
+DEFAULT_WORKLOAD = "cfg3p"
 BPS = {0: 8, 1: 2, 2: 2, 3: 4}
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E data-sheet peak (MI355X_MICROARCH.md); ~6300 measured copy
+# VALU issue rates measured on MI355X (scripts/ubench_valu.hip): ns per wave-instruction per SIMD; v_pk_*_f32 measures 2.0,
+# i.e. no faster than two scalar ops, so a packed op is priced as two f32 slots
+T_F32_NS, T_F64_NS = 1.0, 2.0
+LANES_PER_CHIP = 64 * 4 * 256          # 64 lanes x 4 SIMDs x 256 CUs
+
+
+def valu_ops_per_sample(cfg, nco_order):
+    """Arithmetic of the exact-order chain per INPUT sample (SURVEY 8(d) formula, refined to instruction classes):
+    f32 lane-operations and f64 lane-operations.  FIR: T/D taps per input sample, 2 components, separately rounded mul and
+    add; NCO (DESIGN.md section 4): 10 (first order) / 13 (second order) f64 ops + 2 f64->f32 converts, complex multiply 6 f32;
+    FFT ~5 W log2 W flops per window; |X| per bin: 2 converts, f64 mul + fma, an IEEE f64 sqrt (= 18 f64 issue slots,
+    measured 36 ns) and a convert; 8-bit unpack: ~2 integer ops per component, cs16: two IEEE f32 divides (~10 slots each)."""
+    fc, D, T = cfg["lp"]
+    W, S = cfg["W"], cfg["S"]
+    f32 = 4.0 * T / D + 5.0 * W * math.log2(W) / (S * D)
+    f64 = 23.0 * W / (S * D)
+    if cfg["shift"] is not None:
+        f32 += 6.0
+        f64 += (13.0 if nco_order == 2 else 10.0) + 2.0
+    f32 += {0: 0.0, 1: 4.0, 2: 6.0, 3: 24.0}[cfg["fmt"]]
+    return f32, f64
+
+
+def valu_roof_msamples(cfg, nco_order):
+    f32, f64 = valu_ops_per_sample(cfg, nco_order)
+    ns_per_lane_sample = f32 * T_F32_NS + f64 * T_F64_NS
+    return LANES_PER_CHIP / (ns_per_lane_sample * 1e-9) / 1e6, f32, f64
 
 
 def synth_slab(torch, fmt, first, count, seed, device):
     """Deterministic synthetic IQ (tone at -shift + FSK-ish sign flips + noise + DC), generated on
     the device in chunks so nothing large crosses PCIe."""
+    import numpy as np
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     chunk = 1 << 24
@@ -77,14 +112,11 @@ def cpu_baseline(cfg, slab_bytes, target_s=12.0):
     from oracle import oracle as O
     O.lib().qo_set_lowpass_closed_form(0)      # complex_convolve over every non-decimated position
     try:
-        def build():
-            ch = O.Chain.from_bytes(slab_bytes, cfg["fmt"], cfg["sr"])
-            if cfg["shift"] is not None:
-                ch = ch.shift(cfg["shift"])
-            if cfg["lp"] is not None:
-                ch = ch.lowpass(*cfg["lp"])
-            return ch
-        ch = build()
+        ch = O.Chain.from_bytes(slab_bytes, cfg["fmt"], cfg["sr"])
+        if cfg["shift"] is not None:
+            ch = ch.shift(cfg["shift"])
+        if cfg["lp"] is not None:
+            ch = ch.lowpass(*cfg["lp"])
         total = O.lib().qo_spark_window_count(ch.len(), cfg["W"], cfg["S"])
         probe = min(total, 16)
         t0 = time.perf_counter()
@@ -99,12 +131,12 @@ def cpu_baseline(cfg, slab_bytes, target_s=12.0):
     D = cfg["lp"][1] if cfg["lp"] else 1
     samples = n * cfg["S"] * D
     return dict(value=samples / dt / 1e6, unit="Msamples/s", cores=1, kind="port",
-                sample=f"{n} consecutive windows ({samples} input samples, {dt:.1f} s) of the same workload, "
+                sample=f"{n} consecutive windows ({samples} input samples, {dt:.1f} s) from the middle of the same stream, "
                        "oracle in reference-literal mode (per-window fetch, f64 sin/cos per sample, "
                        "complex_convolve over every non-decimated position), 1 thread")
 
 
-def cpu_allcores(cfg, slab_bytes, target_s=8.0):
+def cpu_allcores(cfg, slab_bytes, target_s=6.0):
     """The same oracle in its cheapest exact form (FIR only at the decimated positions, same rounding order) on every
     host core the process may use: windows are independent, so threads take window ranges (ctypes releases the GIL).
     A second, friendlier CPU figure next to `cpu_baseline` (which keeps the reference's own cost class and thread count)."""
@@ -126,6 +158,7 @@ def cpu_allcores(cfg, slab_bytes, target_s=8.0):
     ch.spark_fft(cfg["W"], cfg["S"], max_windows=probe, want_codes=False)
     per_win = max((time.perf_counter() - t0) / probe, 1e-9)
     per_thread = int(max(1, min(total // cores, target_s / per_win)))
+
     def work(k):
         ch.spark_fft(cfg["W"], cfg["S"], first_window=k * per_thread, max_windows=per_thread, want_codes=False)
     t0 = time.perf_counter()
@@ -139,45 +172,44 @@ def cpu_allcores(cfg, slab_bytes, target_s=8.0):
                        f"positions only (same products, same order), {cores} threads over window ranges")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed launches before the warmup steps (clock ramp)")
-    ap.add_argument("--samples-log2", type=int, default=None, help="override samples per GPU (2^k); rehearsals only")
-    ap.add_argument("--rehearse", action="store_true",
-                    help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0, halo staged through the host")
-    args = ap.parse_args()
+# ------------------------------------------------------------------ self-launch (python bench.py --gpus N, no launcher)
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Parent of a self-launched multi-rank run.  Nothing here imports torch or touches the GPU: the parent only starts
+    N fresh rank processes (one per GPU; every rank on cuda:0 with --rehearse / on the CPU with --stub), relays rank 0's
+    JSON line and fails if any rank fails.  Never re-execs itself."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for ln in (out0 or "").splitlines():              # rank 0's JSON line; library chatter on its stdout (gloo) goes to stderr
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------ one measurement
+
+def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu):
+    import numpy as np
     import torch
     import quadrs_amd as Q
     from quadrs_amd import shard as SH
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dev_index = 0 if args.rehearse else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
-
-    cfg = dict(WORKLOADS[args.workload])
-    if args.samples_log2 is not None:
-        cfg["n"] = 1 << args.samples_log2
     fmt, bps = cfg["fmt"], BPS[cfg["fmt"]]
     n_total = cfg["n"] * world                       # weak scaling: one slab per GPU
     plan = Q.Plan(fmt, cfg["sr"], n_total, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
@@ -185,7 +217,7 @@ def main():
     shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, info.tile_windows)
     me = shards[rank]
 
-    if args.workload == "cfg4":
+    if name == "cfg4":
         # configs[3]: `gen` with 64 cosines @100 Msps (f_k = (k-32)*1 562 500 + 390 625 Hz), generated on
         # the device by the engine's own Gen kernel, outside the timed region
         own = torch.empty(me.own_count, 2, dtype=torch.float32, device=device)
@@ -193,6 +225,7 @@ def main():
         piece = 1 << 28
         for a in range(0, me.own_count, piece):
             Q.gen_device(tones, cfg["sr"], me.own_first + a, own[a:a + piece])
+        torch.cuda.synchronize()
     else:
         own = synth_slab(torch, fmt, me.own_first, me.own_count, 0x5EED0002 + rank, device)
     own_u8 = own.view(torch.uint8).reshape(-1)
@@ -202,20 +235,19 @@ def main():
         slab = SH.exchange(own_u8.cpu(), shards, rank, bps, dist).to(device)         # gloo: staged through the host
     else:
         slab = SH.exchange(own_u8, shards, rank, bps, dist)                          # halo over RCCL/xGMI, once
-    del own
+    del own, own_u8
     nw = me.w1 - me.w0
     out = torch.empty(nw, cfg["W"], dtype=torch.float32, device=device)
 
     def step():
         plan.run_device(slab, out, me.w0, nw, src_first=me.need_first, src_count=me.need_count)
 
-    # settle: the first launches of a process run at ramping clocks (a cfg2 step is ~0.27 ms, so W warmup steps
-    # alone can end before the GPU leaves its idle state); untimed, before the W warmup steps of the contract
+    # settle: the first launches of a process run at ramping clocks; untimed, before the W warmup steps of the contract
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < args.settle:
         step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -226,7 +258,7 @@ def main():
     # ~2.5 us of GPU-side gap (scripts/launch_gap.py), so sampling keeps `value` within 0.3 % of an unmarked loop.
     ev = {}
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         if i % 4 == 0:
             ev[i] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[i][0].record()       # same stream the ABI launches on (torch's current stream)
@@ -244,46 +276,172 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
-
     finite = bool(torch.isfinite(out).all().item())
+
+    res = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
+        ms_per_step = elapsed / steps * 1e3
         # input samples every rank pushed through the chain per step (window starts advance S*D)
         samples_total = sum((s.w1 - s.w0) * info.raw_step for s in shards)
+        samples_rank = nw * info.raw_step
         alg_bytes = me.need_count * bps + nw * cfg["W"] * 4        # per launch on this rank: read once + norms written
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        nco_order = 0 if cfg["shift"] is None else (2 if abs(info.ratio) * n_total > 134217728.0 else 1)
+        valu_ms_roof, f32_ops, f64_ops = valu_roof_msamples(cfg, nco_order)
+        kernel_msamples = samples_rank / (kernel_ms * 1e-3) / 1e6
+        hbm_roof_msamples = HBM_PEAK_GBPS * 1e9 / (alg_bytes / samples_rank) / 1e6
+        hbm_frac, valu_frac = achieved / HBM_PEAK_GBPS, kernel_msamples / valu_ms_roof
+        bound = "hbm" if hbm_roof_msamples <= valu_ms_roof else "valu"
+        # the figure rocprofv3 measured for this workload in the latest committed profile round (profiles/): NOT measured in
+        # this run, hence its own key; `traffic` (in-run PMC) stays null
+        traffic_profiled = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get("workloads", {}).get(args.workload)        # per-workload PMC result of the latest profile round
+                ent = tj.get("workloads", {}).get(name)
                 if ent and args.samples_log2 is None and world == 1:
-                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_profiled = {"hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "source": ent.get("source", "profiles/")}
             except Exception:
-                traffic = None
+                traffic_profiled = None
+        roof = {"bound": bound, "kernel": "qd::k_chain", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                "traffic": None, "traffic_profiled": traffic_profiled,
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac},
+                "valu": {"achieved": kernel_msamples, "peak": valu_ms_roof, "unit": "Msamples/s", "frac": valu_frac,
+                         "f32_ops_per_sample": f32_ops, "f64_ops_per_sample": f64_ops,
+                         "issue_ns_per_wave_instr": {"f32": T_F32_NS, "f64": T_F64_NS},
+                         "note": "exact-order arithmetic at the issue rates scripts/ubench_valu.hip measured; v_pk_*_f32 = two f32 slots"}}
+        if bound == "hbm":
+            roof.update(achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=hbm_frac)
+        else:
+            # the VALU roof in TFLOP/s: every lane-operation of the count above is one flop (separately rounded mul / add, f64 ops
+            # priced at their issue cost of two f32 slots), so peak = lanes / 1 ns = 65.5 TFLOP/s of unfused f32 issue
+            slots = f32_ops + 2.0 * f64_ops
+            roof.update(achieved=kernel_msamples * 1e6 * slots / 1e12, peak=LANES_PER_CHIP / T_F32_NS * 1e9 / 1e12, unit="TFLOP/s", frac=valu_frac)
+        res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
+               "outputs_finite": finite, "kernel_kind": int(info.kernel_kind), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
+        if with_cpu:
+            nwin_cpu = int(min(nw, max(64, (1 << 30) // (info.raw_step * bps))))     # at most 1 GiB of the stream goes to the host
+            first, count = plan.src_range(me.w0 + (nw - nwin_cpu) // 2, nwin_cpu)
+            host = slab[(first - me.need_first) * bps:(first - me.need_first + count) * bps].cpu().numpy().tobytes()
+            res["cpu_baseline"] = cpu_baseline(cfg, host, args.cpu_seconds)
+            res["cpu_allcores"] = cpu_allcores(cfg, host)        # informational: cheapest exact CPU form on every host core
+    plan.close()
+    del slab, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def stub_rank(args, rank, world):
+    """--stub: the launch / rendezvous / barrier / max-over-ranks skeleton with a sleep for a step, on the CPU (gloo).
+    Covers the self-spawn path in the CPU test suite; prints a line that says so."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub (no GPU work: launch-path rehearsal)",
+                          "config": {"workload": "stub"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == args.stub_fail_rank:
+        sys.exit(3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configs (default one-GPU run only)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed launches before the warmup steps (clock ramp)")
+    ap.add_argument("--samples-log2", type=int, default=None, help="override samples per GPU (2^k); rehearsals only")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0, halo staged through the host")
+    ap.add_argument("--stub", action="store_true", help="launch-path rehearsal on the CPU: no GPU work, gloo, a sleep per step")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help="(tests) this rank of a --stub run exits non-zero at the end")
+    args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # no launcher: start the ranks ourselves, before torch / the GPU are touched in this process
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.stub:
+        return stub_rank(args, rank, world)
+
+    import torch
+    dev_index = 0 if args.rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+
+    cfg = dict(WORKLOADS[args.workload])
+    if args.samples_log2 is not None:
+        cfg["n"] = 1 << args.samples_log2
+    main_res = measure(args, args.workload, cfg, rank, world, device, dist, args.steps, args.warmup,
+                       with_cpu=(world == 1 and not args.no_cpu_baseline))
+    others = None
+    if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
+        # the other BASELINE configs, briefly (same protocol, fewer steps, no CPU leg): parity-test cases first, bench lines second
+        others = {}
+        for name in ("cfg2", "cfg3", "cfg4"):
+            r = measure(args, name, dict(WORKLOADS[name]), rank, world, device, dist, 8, 2, with_cpu=False)
+            others[name] = {"value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"], "steps": 8, "warmup": 2,
+                            "bound": r["roofline"]["bound"], "hbm_frac": r["roofline"]["hbm"]["frac"], "valu_frac": r["roofline"]["valu"]["frac"],
+                            "kernel_ms": r["roofline"]["kernel_ms"], "config": WORKLOADS[name]["desc"]}
+    if rank == 0:
         line = {
             "metric": "Msamples/s through shift->FIR->FFT chain",
-            "value": samples_total / (elapsed / args.steps) / 1e6,
+            "value": main_res["value"],
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['desc']}", "samples_per_gpu": cfg["n"], "taps": cfg["lp"][2],
                        "decimate": cfg["lp"][1], "width": cfg["W"], "stride": cfg["S"],
                        "parallelism": f"window-range shards x{world}, halo {(cfg['W'] - cfg['S']) * cfg['lp'][1] + cfg['lp'][2]} samples",
-                       "outputs_finite": finite},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "qd::k_chain", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
+                       "outputs_finite": main_res["outputs_finite"], "kernel_kind": main_res["kernel_kind"],
+                       "tile_windows": main_res["tile_windows"], "threads": main_res["threads"]},
+            "roofline": main_res["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            nwin_cpu = min(nw, 1 << 18)
-            first, count = plan.src_range(me.w0 + (nw - nwin_cpu) // 2, nwin_cpu)
-            host = slab[(first - me.need_first) * bps:(first - me.need_first + count) * bps].cpu().numpy().tobytes()
-            line["cpu_baseline"] = cpu_baseline(cfg, host, args.cpu_seconds)
-            line["cpu_allcores"] = cpu_allcores(cfg, host)        # informational: cheapest exact CPU form on every host core
+        for k in ("cpu_baseline", "cpu_allcores"):
+            if k in main_res:
+                line[k] = main_res[k]
+        if others:
+            line["others"] = others
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

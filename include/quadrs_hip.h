@@ -39,8 +39,10 @@ typedef enum {
 /* FileFormat, src/lib.rs:61-74 */
 typedef enum { QD_FMT_CF32 = 0, QD_FMT_CS8 = 1, QD_FMT_CU8 = 2, QD_FMT_CS16 = 3 } qd_format;
 
-/* where a buffer lives */
-typedef enum { QD_MEM_HOST = 0, QD_MEM_DEVICE = 1 } qd_mem;
+/* where a buffer lives.  QD_MEM_HOST_PINNED: host memory the HIP runtime can DMA from / to directly — allocated by
+ * qd_host_alloc, registered by qd_host_register (e.g. an mmap of the file `from` opened, src/samples.rs:51-61), or
+ * pinned by the caller's own HIP runtime; the host-resident path then skips its pageable -> pinned staging copy. */
+typedef enum { QD_MEM_HOST = 0, QD_MEM_DEVICE = 1, QD_MEM_HOST_PINNED = 2 } qd_mem;
 
 /* what the fused chain leaves per FFT window */
 typedef enum {
@@ -58,6 +60,13 @@ const char *qd_last_error(void);
 const char *qd_version(void);
 int qd_device_count(int *count);
 int qd_set_device(int device);
+
+/* Stream (a hipStream_t, may be NULL) the fine-grained calls of THIS thread enqueue on; with QD_MEM_DEVICE buffers they
+ * then return without synchronising (stream order is the only ordering), with host buffers they return after the
+ * copy back.  Temporaries come from a process-wide workspace pool (no hipMalloc / hipFree per call);
+ * qd_release_workspaces frees the pool's idle buffers and cached plans. */
+int qd_set_stream(void *stream);
+int qd_release_workspaces(void);
 
 /* ------------------------------------------------------------------ fine-grained */
 
@@ -138,7 +147,32 @@ typedef struct {
     uint32_t kernel_kind;     /* 0 generic (runtime geometry), 1 built-in shape-specialised, 2 specialised at plan time (hiprtc) */
 } qd_plan_info;
 
+/* How a plan picks its kernel and moves host-resident streams.  An explicit struct: the shipped library reads no tuning
+ * environment variables (only the location of its on-disk code-object cache: QD_JIT_CACHE / XDG_CACHE_HOME / HOME). */
+typedef enum {
+    QD_KERNEL_AUTO = 0,          /* built-in shape-specialised kernel if one matches, else a cached / worthwhile plan-time build, else generic */
+    QD_KERNEL_GENERIC = 1,       /* runtime-geometry kernels only */
+    QD_KERNEL_SPECIALISE = 2,    /* always specialise at plan time (hiprtc) when no built-in kernel matches */
+    QD_KERNEL_NO_PLAN_TIME = 3   /* built-in or generic; never hiprtc */
+} qd_kernel_policy;
+
+#define QD_MAX_SHARDS 16
+
+typedef struct {
+    uint32_t struct_size;        /* sizeof(qd_plan_options) */
+    int32_t  kernel_policy;      /* qd_kernel_policy */
+    int32_t  nco_order;          /* 0: chosen from |ratio|*n_samples; 1 / 2: force the first / second order NCO correction */
+    uint32_t copy_threads;       /* host threads of the pageable -> pinned staging copy (QD_MEM_HOST); 0: up to 8 */
+    uint64_t chunk_bytes;        /* source bytes per chunk of the host-resident path; 0: 64 MiB */
+    uint32_t n_shards;           /* qd_plan_run_sharded*: number of window-range shards; 0 or 1: the current device only */
+    int32_t  shard_device[QD_MAX_SHARDS];   /* HIP device of shard g (a device may serve several shards) */
+    uint32_t tile_hint[6];       /* tuning: force a plan-time build with this tiling — windows per tile, threads (256 /
+                                    512 / 1024), FIR outputs per lane, FIR block taps, waves per SIMD the build is register-
+                                    budgeted for, LDS pad elements per row (1 / 2); all 0: the library's own choice */
+} qd_plan_options;
+
 int qd_plan_create(const qd_chain_desc *desc, qd_plan **plan);
+int qd_plan_create_ex(const qd_chain_desc *desc, const qd_plan_options *options, qd_plan **plan);
 int qd_plan_destroy(qd_plan *plan);
 int qd_plan_get_info(const qd_plan *plan, qd_plan_info *info);
 /* taps the plan designed (T floats), for inspection */
@@ -154,9 +188,51 @@ int qd_plan_src_range(const qd_plan *plan, uint64_t first_window, uint64_t n_win
  * out receives n_windows * out_bytes_per_window bytes.
  * Device buffers: the kernels are enqueued on `stream` (a hipStream_t, may be NULL) and the
  * call returns without synchronising.  Host buffers: chunked, double-buffered
- * hipMemcpyAsync in and out; returns after the last copy completed. */
+ * hipMemcpyAsync in and out; returns after the last copy completed.  QD_MEM_HOST goes through a
+ * pinned staging ring (a multi-threaded memcpy each way); QD_MEM_HOST_PINNED is copied from / to
+ * directly.  src and out may be HOST and HOST_PINNED in any combination. */
 int qd_plan_run(qd_plan *plan, const void *src, int src_mem, uint64_t src_first, uint64_t src_count,
                 uint64_t first_window, uint64_t n_windows, void *out, int out_mem, void *stream);
+
+/* Multi-GPU in one process (no Python, no collective).  The sink's windows are split into n_shards contiguous,
+ * tile-aligned ranges (the reference's sink loop src/fft.rs:28-65 has no cross-window state); shard g runs on
+ * options.shard_device[g] on its own streams, and the outputs concatenate to exactly the bytes of a one-device run.
+ *   qd_plan_shard_info     window range and source range of shard g: it OWNS samples [own_first, +own_count) (disjoint,
+ *                          in order) and additionally reads `halo` = (W-S)*D+T samples that the next shard owns.
+ *   qd_plan_run_sharded    host-resident stream (QD_MEM_HOST / QD_MEM_HOST_PINNED): every shard's chunks, halo included,
+ *                          are copied straight from the host buffer — the "host-side halo" of SURVEY section 5; one
+ *                          host thread per shard drives that device's double-buffered ring.  Returns when all are done.
+ *   qd_plan_run_sharded_device  device-resident, pre-split stream: slabs[g] is a buffer ON shard g's device that holds
+ *                          the samples shard g owns and has room for `halo` more behind them; the halo is fetched from
+ *                          the next shard's slab with hipMemcpyPeerAsync (xGMI when the devices differ), then the chain
+ *                          runs; outs[g] (on the same device) receives that shard's windows.  sync != 0 waits for all.
+ */
+typedef struct {
+    uint64_t w0, w1;             /* windows [w0, w1) of the sink's loop */
+    uint64_t own_first, own_count, halo;
+    int32_t  device;
+    int32_t  _pad;
+} qd_shard_info;
+int qd_plan_shard_info(const qd_plan *plan, uint32_t shard, qd_shard_info *info);
+int qd_plan_run_sharded(qd_plan *plan, const void *src, int src_mem, void *out, int out_mem);
+int qd_plan_run_sharded_device(qd_plan *plan, void *const *slabs, void *const *outs, int sync);
+
+/* Host-side figures of the most recent host-resident run of the plan (qd_plan_run with host buffers, or one shard of
+ * qd_plan_run_sharded): the survey's qd_plan_stats. */
+typedef struct {
+    double   wall_ms;            /* whole call */
+    double   stage_ms;           /* host time in the pageable <-> pinned staging copies (0 for QD_MEM_HOST_PINNED) */
+    uint64_t bytes_h2d, bytes_d2h;
+    uint32_t chunks;
+    uint32_t _pad;
+} qd_plan_stats;
+int qd_plan_get_stats(const qd_plan *plan, qd_plan_stats *stats);
+
+/* Pinned host memory for QD_MEM_HOST_PINNED: allocate, or register memory the caller already has (an mmap'ed file). */
+int qd_host_alloc(size_t bytes, void **ptr);
+int qd_host_free(void *ptr);
+int qd_host_register(void *ptr, size_t bytes);
+int qd_host_unregister(void *ptr);
 
 /* HIP-event timing of the chain kernel of the most recent device-resident qd_plan_run,
  * taken on the stream it was launched on.  Enable before the run; the query synchronises. */

@@ -8,7 +8,9 @@ LIB_PATH = os.environ.get("QD_LIB_PATH") or os.path.join(_HERE, "libquadrs_hip.s
 
 OK, ERR_INVALID, ERR_PANIC, ERR_SHORT, ERR_HIP, ERR_UNSUPPORTED = range(6)
 FMT_CF32, FMT_CS8, FMT_CU8, FMT_CS16 = 0, 1, 2, 3
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALISE, KERNEL_NO_PLAN_TIME = 0, 1, 2, 3
+MAX_SHARDS = 16
 EPI_NORMS_F32, EPI_GLYPH_U8, EPI_BUCKET2_U8, EPI_CF32_BLOCKS = 0, 1, 2, 3
 
 # every symbol include/quadrs_hip.h declares
@@ -18,6 +20,9 @@ SYMBOLS = [
     "qd_plan_create", "qd_plan_destroy", "qd_plan_get_info", "qd_plan_get_taps", "qd_plan_src_range",
     "qd_plan_run", "qd_plan_set_timing", "qd_plan_last_kernel_ms", "qd_gen", "qd_take_fft",
     "qd_device_alloc", "qd_device_free", "qd_device_copy",
+    "qd_set_stream", "qd_release_workspaces", "qd_plan_create_ex", "qd_plan_shard_info", "qd_plan_run_sharded",
+    "qd_plan_run_sharded_device", "qd_plan_get_stats", "qd_host_alloc", "qd_host_free", "qd_host_register",
+    "qd_host_unregister",
 ]
 
 
@@ -38,6 +43,28 @@ class PlanInfo(C.Structure):
         ("out_bytes_per_window", C.c_uint64), ("raw_per_window", C.c_uint64), ("raw_step", C.c_uint64),
         ("ratio", C.c_double), ("tile_windows", C.c_uint32), ("threads", C.c_uint32),
         ("lds_bytes", C.c_uint32), ("kernel_kind", C.c_uint32),
+    ]
+
+
+class PlanOptions(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("kernel_policy", C.c_int32), ("nco_order", C.c_int32),
+        ("copy_threads", C.c_uint32), ("chunk_bytes", C.c_uint64), ("n_shards", C.c_uint32),
+        ("shard_device", C.c_int32 * MAX_SHARDS), ("tile_hint", C.c_uint32 * 6),
+    ]
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [
+        ("w0", C.c_uint64), ("w1", C.c_uint64), ("own_first", C.c_uint64), ("own_count", C.c_uint64),
+        ("halo", C.c_uint64), ("device", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [
+        ("wall_ms", C.c_double), ("stage_ms", C.c_double), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64),
+        ("chunks", C.c_uint32), ("_pad", C.c_uint32),
     ]
 
 
@@ -93,6 +120,17 @@ def lib():
             "qd_device_free": (i32, [vp]),
             "qd_device_copy": (i32, [vp, i32, vp, i32, sz]),
             "qd_take_fft": (i32, [vp, u64, sz, u64, i32, u64, u64, sz, i32, sz, vp, i32]),
+            "qd_set_stream": (i32, [vp]),
+            "qd_release_workspaces": (i32, []),
+            "qd_plan_create_ex": (i32, [C.POINTER(ChainDesc), C.POINTER(PlanOptions), C.POINTER(vp)]),
+            "qd_plan_shard_info": (i32, [vp, C.c_uint32, C.POINTER(ShardInfo)]),
+            "qd_plan_run_sharded": (i32, [vp, vp, i32, vp, i32]),
+            "qd_plan_run_sharded_device": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32]),
+            "qd_plan_get_stats": (i32, [vp, C.POINTER(PlanStats)]),
+            "qd_host_alloc": (i32, [sz, C.POINTER(vp)]),
+            "qd_host_free": (i32, [vp]),
+            "qd_host_register": (i32, [vp, sz]),
+            "qd_host_unregister": (i32, [vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

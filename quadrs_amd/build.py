@@ -75,6 +75,33 @@ def build(force=False, verbose=False, extra=()):
     return OUT
 
 
+DEV_OUT = os.path.join(HERE, "libquadrs_hip_dev.so")
+
+
+def build_dev(verbose=False, extra=()):
+    """Development library (-DQD_DEVELOP): the timing-only ablation bits of the chain kernel and the QD_DEBUG_SKIP /
+    QD_WG_PER_CU / QD_JIT_FLAGS / QD_JIT_NOSLP / QD_JIT_DUMP environment knobs exist only here.  The probe scripts under
+    scripts/ load it through QD_LIB_PATH; tests, bench.py and the CLI use the shipped library."""
+    obj_dir = os.path.join(ROOT, "build", "obj_dev")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs, procs = [], []
+    for src, more in SRC:
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        cmd = [hipcc()] + FLAGS + more + ["-DQD_DEVELOP"] + list(extra) + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_OUT] + objs + ["-lhiprtc", "-ldl"])
+    return DEV_OUT
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(OUT)
+    if "--dev" in sys.argv:
+        print(build_dev(verbose=True, extra=["-DQD_STAMP"] if "--stamp" in sys.argv else ()))
+    else:
+        build(force="--force" in sys.argv, verbose=True)
+        print(OUT)

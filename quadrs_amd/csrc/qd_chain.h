@@ -45,6 +45,14 @@ namespace qd {
 
 constexpr int kThreads = 256;
 
+// Timing-only ablation bits (ChainParams::dbg) exist in development builds (-DQD_DEVELOP: libquadrs_hip_dev.so, the
+// probe scripts) only; in the shipped library the tests compile to nothing.
+#ifdef QD_DEVELOP
+#define QD_DBG(P, bit) (((P).dbg & (bit)) != 0)
+#else
+#define QD_DBG(P, bit) false
+#endif
+
 // Wave-uniform read-only tables (taps, row bases) are read through the constant address space
 // so that hipcc emits scalar loads (s_load_dwordx8) instead of one vector load per lane.
 typedef const float __attribute__((address_space(4))) *const_f32_p;
@@ -77,7 +85,7 @@ struct ChainParams {
     float2 tw16_1, tw16_2, tw16_3;
     uint32_t epi;              // qd_epilogue
     float gstep;               // glyph epilogue: (rmax - rmin) / 7.0f, computed on the host (see glyph_code)
-    uint32_t dbg;              // timing-only ablation bits (QD_DEBUG_SKIP; 1 NCO, 2 FIR, 4 FFT, 8 hypot, 16 output store, 32 LDS staging); 0 in every real run
+    uint32_t dbg;              // development builds (-DQD_DEVELOP) only: timing-only ablation bits (1 NCO, 2 FIR, 4 FFT, 8 hypot, 16 output store, 32 LDS staging); else only the never-true liveness sentinel reads it
     unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
     const uint64_t *row_offsets; // take_fft (src/ffts.rs:59-60): window w starts at row_offsets[w] (generic kernels, G = 1)
     const float *window;         // take_fft windowing (src/ffts.rs:64-68): sample k of a window is scaled by window[k]
@@ -334,7 +342,7 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
         x[3] = make_float2(unpack_cs16(v.w & 0xffffu), unpack_cs16(v.w >> 16));
     }
     if constexpr (NCO != 0) {
-        if (!(P.dbg & 1)) {
+        if (!QD_DBG(P, 1)) {
             float2 m[SPL];
             nco_mul_n<NCO == 2, SPL>(rb, lr, P.ratio, m);          // the SPL f64 chains issued interleaved
 #pragma unroll
@@ -344,7 +352,7 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
     // Additive addressing: rel is a multiple of PD (n_start and ROW both are) and SPL divides PD, so
     // pad(rel + t) = pad_s(rel) + pad(t) and a lane's SPL samples are contiguous in LDS.
     const bool additive = geo.pshift != 0xffffffffu && geo.PD >= (uint32_t)SPL && geo.PD <= ROW;
-    if (P.dbg & 32) {            // timing-only ablation: consume the row without the LDS store
+    if (QD_DBG(P, 32)) {            // timing-only ablation: consume the row without the LDS store
         asm volatile("" :: "v"(x[0].x), "v"(x[0].y), "v"(x[SPL - 1].x), "v"(x[SPL - 1].y));
         return;
     }
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         // compile-time for shape-specialised kernels (so only ONE FIR variant is instantiated and the long
         // unrolled chain stays in registers), a wave-uniform runtime flag for the generic ones
         bool shared;
-        if constexpr (GeoT::kFixed) shared = GeoT::kShared; else shared = HAS_FIR && S < W && ntrunc <= S && !(P.dbg & 2) && P.epi != 3;
+        if constexpr (GeoT::kFixed) shared = GeoT::kShared; else shared = HAS_FIR && S < W && ntrunc <= S && !QD_DBG(P, 2) && P.epi != 3;
         if constexpr (!GeoT::kFixed || GeoT::kShared) if (shared) {
             const uint32_t Q = (g_cnt - 1) * S + W;
             if constexpr (GeoT::kFixed && GeoT::kFirTile > 1) {
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 uint32_t jmax = (W - k) * D + T / 2;
                 if (jmax > T) jmax = T;
                 const float *xp = reinterpret_cast<const float *>(raw + (size_t)(g * S + k + geo.a0) * Dp) + part;
-                const float v = (P.dbg & 2) ? xp[0] : fir_comp<GeoT>(xp, jmax, tapl);     // dbg: timing-only ablation
+                const float v = QD_DBG(P, 2) ? xp[0] : fir_comp<GeoT>(xp, jmax, tapl);     // dbg: timing-only ablation
                 const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
                 reinterpret_cast<float *>(fb + (g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base))[part] = v;
             }
@@ -1110,7 +1118,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             const uint32_t g = o >> logW, k = o & (W - 1);
             const uint32_t q = g * S + k;
             float accr = 0.f, acci = 0.f;
-            if (HAS_FIR && !(P.dbg & 2)) {
+            if (HAS_FIR && !QD_DBG(P, 2)) {
                 // jmax(k) = min(T, valid - (k*D + c)) with valid = B*D + T (full read of a block of B outputs;
                 // B == W for the FFT sinks, B = 0x1000 > W for the write sink whose tiles are sub-blocks)
                 const uint32_t kb = cf32_out ? (((uint32_t)(w0 + g)) & P.blk_sub_mask) * W + k : k;
@@ -1144,7 +1152,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
         __builtin_amdgcn_s_setprio(3);
         // ---------------- phase 3: FFT (rustfft Radix4: base butterflies, then radix-4 layers)
-        if (!(P.dbg & 4) && !cf32_out) {
+        if (!QD_DBG(P, 4) && !cf32_out) {
             const uint32_t base = geo.base_len;
             const uint32_t log_tpw = logW - geo.log_base;   // base tasks per window = W / base
             const uint32_t n_task = g_cnt << log_tpw;
@@ -1225,14 +1233,14 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << logW);
             for (uint32_t o = tid; o < n_out; o += NT) {
                 const float2 xv = fb[o ^ (W >> 1)];           // fftshift: bin (b + W/2) mod W of the same window
-                const float nm = (P.dbg & 8) ? xv.x : norm_ref(xv);
+                const float nm = QD_DBG(P, 8) ? xv.x : norm_ref(xv);
                 // The store address is uniform base + 32-bit lane offset.  Keep the offset opaque so hipcc does not
                 // hoist a per-lane 64-bit `P.out + tid*4` out of the tile loop: that pair was the kernel's one VGPR
                 // spill, and its scratch reload here carried an s_waitcnt vmcnt(0) — a full drain of the next tile's
                 // prefetch loads in every epilogue.
                 uint32_t oo = o;
                 asm volatile("" : "+v"(oo));
-                if (P.dbg & 16) { asm volatile("" :: "v"(nm)); continue; }      // timing-only ablation: no output store
+                if (QD_DBG(P, 16)) { asm volatile("" :: "v"(nm)); continue; }      // timing-only ablation: no output store
                 if (P.epi == 0) outf[oo] = nm;
                 else outb[oo] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
             }

@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <algorithm>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <tuple>
 #include <string>
@@ -50,6 +52,14 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr double kPi64 = 3.14159265358979323846264338327950288;
 constexpr float kPi32 = 3.14159265358979323846264338327950288f;
+
+// Tuning / ablation knobs read from the environment exist in development builds only (-DQD_DEVELOP:
+// libquadrs_hip_dev.so, used by scripts/); the shipped library takes its policy from qd_plan_options.
+#ifdef QD_DEVELOP
+const char *dev_env(const char *name) { return getenv(name); }
+#else
+const char *dev_env(const char *) { return nullptr; }
+#endif
 
 uint32_t ilog2(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) ++l; return l; }
 bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
@@ -154,6 +164,62 @@ __global__ void k_gen(const int64_t *cos_hz, uint32_t n_cos, uint64_t sample_rat
     }
 }
 
+// take_fft at a width that is not a power of two (src/ffts.rs:25: FftPlanner::plan_fft_forward takes any length; the
+// egui slider offers 4..4096, src/eui/mod.rs:157).  Bluestein's chirp-z form: X[k] = c[k] * sum_n (x[n] c[n]) b[k-n],
+// c[n] = e^{-i pi n^2 / W}, b = conj(c) — a circular convolution of length M >= 2W-1 (a power of two), done in LDS as
+// forward radix-2 DIF (natural in, bit-reversed out) -> pointwise product with the precomputed spectrum of b (stored
+// bit-reversed, 1/M folded in) -> inverse radix-2 DIT (bit-reversed in, natural out): no permutation pass.
+// One workgroup per output row.  rustfft's own result for such lengths depends on the host's SIMD code path, so there is
+// no bit pattern to match (parity unpinned); tests bound it against an f64 DFT (tests/test_gpu_parity.py).
+__global__ __launch_bounds__(256) void k_bluestein(const float2 *__restrict__ in, uint64_t in_first, const uint64_t *__restrict__ offs,
+                                                   const float *__restrict__ win, uint32_t W, uint32_t M, uint32_t logM,
+                                                   const float2 *__restrict__ chirp, const float2 *__restrict__ Bbr,
+                                                   const float2 *__restrict__ tw, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    float2 *buf = reinterpret_cast<float2 *>(smem_b);
+    const uint32_t tid = threadIdx.x;
+    const uint64_t row = blockIdx.x;
+    const float2 *x = in + (offs[row] - in_first);
+    for (uint32_t n = tid; n < M; n += 256) {
+        float2 v = make_float2(0.f, 0.f);
+        if (n < W) {
+            v = x[n];
+            if (win) v = cscale(v, win[n]);           // *sample *= w_val (src/ffts.rs:64-68), Complex<f32> * f32
+            v = cmul(v, chirp[n]);
+        }
+        buf[n] = v;
+    }
+    __syncthreads();
+    for (uint32_t sh = logM; sh-- > 0;) {             // DIF, half-span h = 2^sh
+        const uint32_t h = 1u << sh;
+        for (uint32_t t = tid; t < M / 2; t += 256) {
+            const uint32_t j = t & (h - 1), i = ((t >> sh) << (sh + 1)) | j;
+            const float2 u = buf[i], v = buf[i + h];
+            buf[i] = cadd(u, v);
+            buf[i + h] = cmul(csub(u, v), tw[j << (logM - 1 - sh)]);
+        }
+        __syncthreads();
+    }
+    for (uint32_t r = tid; r < M; r += 256) buf[r] = cmul(buf[r], Bbr[r]);
+    __syncthreads();
+    for (uint32_t sh = 0; sh < logM; ++sh) {          // DIT with conjugate twiddles
+        const uint32_t h = 1u << sh;
+        for (uint32_t t = tid; t < M / 2; t += 256) {
+            const uint32_t j = t & (h - 1), i = ((t >> sh) << (sh + 1)) | j;
+            const float2 u = buf[i], v = cmul(buf[i + h], cconj(tw[j << (logM - 1 - sh)]));
+            buf[i] = cadd(u, v);
+            buf[i + h] = csub(u, v);
+        }
+        __syncthreads();
+    }
+    const uint32_t half = W / 2;                       // skip(W/2).chain(take(W/2)), src/ffts.rs:72-78
+    for (uint32_t k = tid; k < W; k += 256) {
+        const float2 y = cmul(buf[k], chirp[k]);
+        const uint32_t pos = k >= half ? k - half : k + (W - half);
+        out[row * W + pos] = norm_ref(y);
+    }
+}
+
 // ------------------------------------------------------------------ host arithmetic restated from the reference
 
 // src/filter.rs:86-105 with cutoff from :126-128,:31 — f32 throughout, platform libm
@@ -248,7 +314,6 @@ const FixedEntry kFixed[] = {
 };
 
 const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t D, uint32_t T) {
-    if (getenv("QD_NO_FIXED")) return nullptr;       // tests compare the specialised and generic kernels
     for (const FixedEntry &e : kFixed)
         if (e.fmt == fmt && e.nco == nco && e.W == W && e.S == S && e.D == D && e.T == T) return &e;
     int n_long = 0;
@@ -331,15 +396,17 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     if (hiprtcCreateProgram(&prog, src.c_str(), "qd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *why = "hiprtcCreateProgram failed"; return nullptr; }
     hiprtcAddNameExpression(prog, name);
     const std::string inc = "-I" + dir;
-#ifdef QD_STAMP
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str(), "-DQD_STAMP"};
-#else
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str()};
-#endif
     std::vector<const char *> optv(opts, opts + sizeof opts / sizeof opts[0]);
-    if (k.noslp || getenv("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");   // scalar f32 accumulate chains (see qd_longfir.hip)
+#ifdef QD_STAMP
+    optv.push_back("-DQD_STAMP");
+#endif
+#ifdef QD_DEVELOP
+    optv.push_back("-DQD_DEVELOP");
+#endif
+    if (k.noslp || dev_env("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");   // scalar f32 accumulate chains (see qd_longfir.hip)
     std::vector<std::string> extra;                          // development: QD_JIT_FLAGS="-mllvm -foo ..." appended verbatim
-    if (const char *e = getenv("QD_JIT_FLAGS")) {
+    if (const char *e = dev_env("QD_JIT_FLAGS")) {
         std::string cur;
         for (const char *c = e;; ++c) {
             if (*c == ' ' || *c == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*c) break; }
@@ -351,10 +418,14 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     std::string cache_file;
     {
         uint64_t h = fnv1a(name, strlen(name));
+        int rtc_major = 0, rtc_minor = 0;                      // a code object does not outlive the compiler that made it
+        (void)hiprtcVersion(&rtc_major, &rtc_minor);
+        h = fnv1a(&rtc_major, sizeof rtc_major, h);
+        h = fnv1a(&rtc_minor, sizeof rtc_minor, h);
         for (const char *o : optv) if (o != inc.c_str()) h = fnv1a(o, strlen(o) + 1, h);
         h = fnv1a(hdr1.data(), hdr1.size(), h);
         h = fnv1a(hdr2.data(), hdr2.size(), h);
-        const std::string cdir = getenv("QD_JIT_DUMP") ? std::string() : jit_cache_dir();
+        const std::string cdir = dev_env("QD_JIT_DUMP") ? std::string() : jit_cache_dir();
         if (!cdir.empty()) { char fn[64]; snprintf(fn, sizeof fn, "/%016llx.co", (unsigned long long)h); cache_file = cdir + fn; }
     }
     if (!cache_file.empty()) {
@@ -386,7 +457,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
     std::vector<char> code(cs);
     hiprtcGetCode(prog, code.data());
-    if (const char *dump = getenv("QD_JIT_DUMP")) {          // development: keep the code object for llvm-objdump
+    if (const char *dump = dev_env("QD_JIT_DUMP")) {          // development: keep the code object for llvm-objdump
         if (FILE *f = fopen(dump, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
     }
     hipModule_t mod; hipFunction_t fn = nullptr;
@@ -433,8 +504,21 @@ constexpr size_t kLdsMax = 160 * 1024;
 
 // ------------------------------------------------------------------ plan
 
+// One NCO row table (device): RowBase of the rows [row0, row0 + rows) of `row_len` samples.  A table is only ever
+// rewritten (k_rowtab into the same buffer) or regrown after the stream that last read it has drained.
+struct RowTab {
+    RowBase *d = nullptr;
+    uint64_t cap = 0, row0 = 0, rows = 0;
+    hipStream_t last = nullptr;
+    bool used = false;
+};
+// tables one launch context needs: the main kernel's rows and, for plans whose main kernel is not 256 threads wide,
+// rows laid out for the 256-thread per-sample kernel that takes the windows at an unaligned slab end
+struct NcoTabs { RowTab main, tail; };
+
 struct qd_plan {
     qd_chain_desc d{};
+    qd_plan_options opt{};
     int device = 0;
     bool has_shift = false, has_fir = false;
     uint32_t W = 0, logW = 0, S = 0, D = 1, T = 0;
@@ -452,15 +536,10 @@ struct qd_plan {
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
     int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0, nt = kThreads;
-    // NCO tables
-    double2 *jtab_d = nullptr;
-    RowBase *rowtab_d = nullptr;
-    uint64_t rowtab_row0 = 0, rowtab_rows = 0;
-    // plans whose main kernel uses another workgroup size keep a second pair of NCO tables laid out for the
-    // 256-thread per-sample kernel that takes the windows at an unaligned slab end
-    double2 *jtab256_d = nullptr;
-    RowBase *rowtab256_d = nullptr;
-    uint64_t rowtab256_row0 = 0, rowtab256_rows = 0;
+    uint32_t dbg = 0;                    // development builds: ablation bits, read once at plan creation
+    // NCO tables: lane tables per plan, row tables per launch context (device path; one per slot of the host ring)
+    double2 *jtab_d = nullptr, *jtab256_d = nullptr;
+    NcoTabs tabs_dev, tabs_slot[2];
     // take_fft mode (generic kernels): per-window start offsets and an f32 window, both on the device
     const uint64_t *row_offsets_d = nullptr;
     const float *window_d = nullptr;
@@ -470,8 +549,12 @@ struct qd_plan {
     // host streaming
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
     void *dev_in[2] = {nullptr, nullptr}, *dev_out[2] = {nullptr, nullptr};
-    size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    size_t stage_in_bytes = 0, stage_out_bytes = 0, pin_in_bytes = 0, pin_out_bytes = 0;
     hipStream_t streams[2] = {nullptr, nullptr};
+    qd_plan_stats stats{};
+    // sharded plans (options.n_shards > 1): one child plan per shard, created on that shard's device
+    std::vector<qd_plan *> shards;
+    std::vector<qd_shard_info> shard_info;
     std::mutex mu;
 };
 
@@ -486,26 +569,32 @@ uint64_t out_bytes_per_window(const qd_plan *p) {
     }
 }
 
-int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowBase **tab, uint64_t *row0, uint64_t *nrows, uint64_t n_lo, uint64_t n_hi,
-                      hipStream_t st) {
-    uint64_t r_lo = n_lo / ROW, r_hi = (n_hi + ROW - 1) / ROW + 1;
-    if (*tab && r_lo >= *row0 && r_hi <= *row0 + *nrows) return QD_OK;
-    if (*tab) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(*tab)); *tab = nullptr; }
-    uint64_t rows = r_hi - r_lo;
-    HIPCHK(hipMalloc(tab, rows * sizeof(RowBase)));
-    *row0 = r_lo; *nrows = rows;
-    uint32_t blocks = (uint32_t)((rows + 255) / 256);
-    hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, *tab);
+int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowTab *t, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
+    const uint64_t r_lo = n_lo / ROW, r_hi = (n_hi + ROW - 1) / ROW + 1;
+    if (t->d && r_lo >= t->row0 && r_hi <= t->row0 + t->rows) { t->last = st; t->used = true; return QD_OK; }
+    // The table is about to be rewritten: whatever read it last must have finished.  Work on `st` itself is ordered
+    // behind k_rowtab by the stream; a different stream is drained first.
+    if (t->used && t->last != st) HIPCHK(hipStreamSynchronize(t->last));
+    const uint64_t rows = r_hi - r_lo;
+    if (rows > t->cap) {
+        if (t->d) { if (t->used) HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(t->d)); t->d = nullptr; t->cap = 0; }
+        const uint64_t cap = rows + rows / 8 + 16;            // chunks of a run differ by a row or two: grow once
+        HIPCHK(hipMalloc(&t->d, cap * sizeof(RowBase)));
+        t->cap = cap;
+    }
+    t->row0 = r_lo; t->rows = rows; t->last = st; t->used = true;
+    const uint32_t blocks = (uint32_t)((rows + 255) / 256);
+    hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, t->d);
     HIPCHK(hipGetLastError());
     return QD_OK;
 }
 
-int ensure_rowtab(qd_plan *p, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
-    if (!p->has_shift) return QD_OK;
-    return ensure_rowtab_for(p, p->nt * spl_of(p->d.format), &p->rowtab_d, &p->rowtab_row0, &p->rowtab_rows, n_lo, n_hi, st);
+void free_rowtab(RowTab *t) {
+    if (t->d) (void)hipFree(t->d);
+    *t = RowTab{};
 }
 
-int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src_count, uint64_t first_window,
+int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_first, uint64_t src_count, uint64_t first_window,
                  uint64_t n_windows, uint64_t out_window0, void *out_d, hipStream_t st) {
     if (n_windows == 0) return QD_OK;
     const int fmt = p->d.format;
@@ -516,8 +605,11 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         return fail(QD_ERR_INVALID, "src slab [%llu,+%llu) does not cover samples [%llu,%llu) needed by windows [%llu,+%llu)",
                     (unsigned long long)src_first, (unsigned long long)src_count, (unsigned long long)need0,
                     (unsigned long long)need1, (unsigned long long)first_window, (unsigned long long)n_windows);
-    int rc = ensure_rowtab(p, need0, need1, st);
-    if (rc) return rc;
+    int rc = QD_OK;
+    if (p->has_shift) {
+        rc = ensure_rowtab_for(p, p->nt * spl_of(fmt), &tabs->main, need0, need1, st);
+        if (rc) return rc;
+    }
 
     ChainParams P{};
     P.src = static_cast<const uint8_t *>(src_d);
@@ -541,13 +633,13 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     P.root2 = (float)std::sqrt(0.5);
     P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
     P.ratio = p->ratio;
-    P.rowtab = p->rowtab_d; P.rowtab_row0 = p->rowtab_row0;
+    P.rowtab = tabs->main.d; P.rowtab_row0 = tabs->main.row0;
     P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
     P.out = out_d;
     P.row_offsets = p->row_offsets_d; P.window = p->window_d;
     P.blk_len = p->blk_len ? p->blk_len : p->W; P.blk_sub_mask = p->blk_subs - 1;
     P.tile_extra = p->tile_extra;
-    if (const char *e = getenv("QD_DEBUG_SKIP")) P.dbg = (uint32_t)atoi(e);   // timing-only ablation, never set in tests/bench
+    P.dbg = p->dbg;                                       // 0 except in development builds (QD_DEBUG_SKIP at plan creation)
 #ifdef QD_STAMP
     static unsigned long long *stamps_d = nullptr;
     if (!stamps_d) { HIPCHK(hipMalloc(&stamps_d, 160 * 8)); }
@@ -571,11 +663,10 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
     const bool tail_tables = n_aligned < n_windows && p->nt != kThreads && p->has_shift;
     if (tail_tables) {
         const uint64_t t0 = (first_window + n_aligned) * p->S * p->D;
-        rc = ensure_rowtab_for(p, kThreads * spl, &p->rowtab256_d, &p->rowtab256_row0, &p->rowtab256_rows, t0, need1, st);
+        rc = ensure_rowtab_for(p, kThreads * spl, &tabs->tail, t0, need1, st);
         if (rc) return rc;
     }
-    uint64_t cap = (uint64_t)p->n_cu * p->wg_per_cu;
-    if (const char *e = getenv("QD_WG_PER_CU")) cap = (uint64_t)p->n_cu * (uint64_t)atoi(e);   // tuning knob
+    const uint64_t cap = (uint64_t)p->n_cu * p->wg_per_cu;
     if (p->timing) {
         if (!p->ev_made) { HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1)); p->ev_made = true; }
         HIPCHK(hipEventRecord(p->ev0, st));
@@ -585,7 +676,7 @@ int launch_chain(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src
         const uint64_t w_count = part == 0 ? n_aligned : n_windows - n_aligned;
         if (w_count == 0) continue;
         P.first_window = w_begin; P.n_windows = w_count;
-        if (part == 1 && tail_tables) { P.rowtab = p->rowtab256_d; P.rowtab_row0 = p->rowtab256_row0; P.jtab = p->jtab256_d; }
+        if (part == 1 && tail_tables) { P.rowtab = tabs->tail.d; P.rowtab_row0 = tabs->tail.row0; P.jtab = p->jtab256_d; }
         const uint64_t n_tiles = (w_count + P.G - 1) / P.G;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
@@ -630,7 +721,7 @@ void free_streaming(qd_plan *p) {
         p->pin_in[i] = p->pin_out[i] = p->dev_in[i] = p->dev_out[i] = nullptr;
         p->streams[i] = nullptr;
     }
-    p->stage_in_bytes = p->stage_out_bytes = 0;
+    p->stage_in_bytes = p->stage_out_bytes = p->pin_in_bytes = p->pin_out_bytes = 0;
 }
 
 }  // namespace
@@ -698,7 +789,9 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // second-order term is e^2/2 with |e| <= 1.5 ulp(place); below 2^27 rad that is <= 2.5e-16, inside the
     // scheme's ~4e-16 error budget, above it the second-order kernel is used
     p->nco = !p->has_shift ? 0 : ((std::fabs(p->ratio) * (double)d.n_samples > 134217728.0) ? 2 : 1);
-    if (const char *e = getenv("QD_NCO_ORDER")) { int v = atoi(e); if (p->has_shift && (v == 1 || v == 2)) p->nco = v; }
+    if (p->has_shift && (p->opt.nco_order == 1 || p->opt.nco_order == 2)) p->nco = p->opt.nco_order;
+    if (const char *e = dev_env("QD_DEBUG_SKIP")) p->dbg = (uint32_t)atoi(e);     // development builds: timing-only ablation
+    const int policy = p->opt.kernel_policy;
 
     // tile geometry: a shape-specialised kernel dictates G; otherwise pick G for LDS / lane use
     uint32_t G = 1, raw_elems = 0;
@@ -706,27 +799,29 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (lds_for(1, p->W, p->S, p->D, T_lds, &raw_elems) > kLdsMax)
         return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
                     (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
-    p->fixed = (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS) ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
-    // QD_TUNE=G:NT:FIRR:FIRB:LB:PAD (development): force a plan-time build with this tiling instead of the table / heuristics
-    // (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256; PAD = LDS pad elements per row)
+    p->fixed = (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC) ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
+    // qd_plan_options.tile_hint = {G, NT, FIRR, FIRB, LB, PAD}: force a plan-time build with this tiling instead of the table /
+    // heuristics (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256; PAD = LDS pad elements per row)
     uint32_t tune[6] = {0, 0, 1, 8, 4, 1};
     bool tuned = false;
-    if (const char *e = getenv("QD_TUNE")) {
-        if (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && sscanf(e, "%u:%u:%u:%u:%u:%u", &tune[0], &tune[1], &tune[2], &tune[3], &tune[4], &tune[5]) >= 2 && tune[4] >= 1 && tune[4] <= 8 &&
-            tune[0] >= 1 && (tune[1] == 256 || tune[1] == 512 || tune[1] == 1024) && (tune[5] == 1 || tune[5] == 2) &&
-            lds_for(tune[0], p->W, p->S, p->D, T_lds, nullptr, tune[5]) <= kLdsMax) {
-            tuned = true;
-            p->fixed = nullptr;
-        }
+    if (p->opt.tile_hint[0] || p->opt.tile_hint[1]) {
+        const uint32_t *h = p->opt.tile_hint;
+        const uint32_t t6[6] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u};
+        if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t6[4] >= 1 && t6[4] <= 8 && t6[0] >= 1 &&
+              (t6[1] == 256 || t6[1] == 512 || t6[1] == 1024) && (t6[5] == 1 || t6[5] == 2) &&
+              lds_for(t6[0], p->W, p->S, p->D, T_lds, nullptr, t6[5]) <= kLdsMax))
+            return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u} does not fit this chain", t6[0], t6[1], t6[2], t6[3], t6[4], t6[5]);
+        for (int i = 0; i < 6; ++i) tune[i] = t6[i];
+        tuned = true;
+        p->fixed = nullptr;
     }
     // Plan-time specialisation is wanted for shapes without a built-in kernel once the stream is big enough to
-    // repay the ~0.3 s compile (QD_JIT=0 off, =1 always).
-    const char *jenv = getenv("QD_JIT");
-    const int jmode = jenv ? atoi(jenv) : -1;                       // -1 auto, 0 off, 1 force
+    // repay the ~0.3 s compile (qd_plan_options.kernel_policy: QD_KERNEL_SPECIALISE always, QD_KERNEL_NO_PLAN_TIME /
+    // QD_KERNEL_GENERIC never).
     const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
-    const bool jit_ok = !getenv("QD_NO_FIXED") && d.epilogue != QD_EPI_CF32_BLOCKS && jmode != 0;
+    const bool jit_ok = d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME;
     // a cached build is always used; a NEW build only when forced or when the stream is at least 1 GiB
-    const bool may_compile = jmode == 1 || tuned || in_bytes >= (1ull << 30);
+    const bool may_compile = policy == QD_KERNEL_SPECIALISE || tuned || in_bytes >= (1ull << 30);
     auto make_key = [&](uint32_t g, int nt, int lb, int noslp, uint32_t padv) {
         const uint64_t ROW = (uint64_t)nt * spl_of(d.format);
         const uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
@@ -780,7 +875,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const bool want = !heavy && (tuned || (!p->fixed && jit_ok));
         if (want) {
             p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad), &p->jit_note, may_compile);
-            if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "QD_TUNE build failed: %s", p->jit_note.c_str());
+            if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "tile_hint build failed: %s", p->jit_note.c_str());
         }
     }
     hipDeviceProp_t prop;
@@ -790,16 +885,18 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->nt > kThreads) { int by_threads = 2048 / p->nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
     if (tuned || heavy) { int by_regs = (jit_lb * 4 * 64) / p->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
-    if (p->jit_fn && p->geo.lds_bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->geo.lds_bytes) != hipSuccess)
+    // Dynamic-LDS limit: the kernels are process-global objects shared by every plan, so the attribute is set to the
+    // hardware maximum (160 KiB), never to one plan's tile — a later plan with a smaller tile must not lower the limit
+    // under a live plan with a larger one (tests/test_gpu_robustness.py::test_two_live_plans_with_different_lds).
+    if (p->jit_fn) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) != hipSuccess)
             p->jit_fn = nullptr;     // fall back to the generic kernel
     }
     if (heavy && !p->jit_fn) p->nt = kThreads;
     for (chain_fn f : {p->fn, p->fn_unaligned}) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)p->geo.lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
         if (e != hipSuccess)
-            return fail(QD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS %zu): %s", p->geo.lds_bytes, hipGetErrorString(e));
+            return fail(QD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS %zu): %s", kLdsMax, hipGetErrorString(e));
     }
 
     // constant tables
@@ -831,9 +928,52 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
 }
 
 
-int qd_plan_create(const qd_chain_desc *desc, qd_plan **out) {
+namespace {
+struct DeviceGuard {                       // hipSetDevice is per host thread: run a plan on the device it was made on
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+// Equal, contiguous, tile-aligned window ranges (quadrs_amd/shard.py::partition states the same rule for the
+// one-process-per-GPU path): shard g owns the source samples from its first window's start up to the next shard's
+// first window's start, and reads `halo` samples beyond that.
+void partition_windows(uint64_t n_windows, uint32_t n_shards, uint64_t step, uint64_t rpw, uint32_t tile, std::vector<qd_shard_info> *out) {
+    out->assign(n_shards, qd_shard_info{});
+    uint64_t per = (n_windows + n_shards - 1) / n_shards;
+    per = (per + tile - 1) / tile * tile;
+    const uint64_t total_end = n_windows ? (n_windows - 1) * step + rpw : 0;
+    for (uint32_t g = 0; g < n_shards; ++g) {
+        qd_shard_info &s = (*out)[g];
+        s.w0 = std::min<uint64_t>(n_windows, (uint64_t)g * per);
+        s.w1 = std::min<uint64_t>(n_windows, (uint64_t)(g + 1) * per);
+        uint64_t own_first = s.w0 * step;
+        uint64_t own_end = (g + 1 < n_shards && s.w1 < n_windows) ? s.w1 * step : total_end;
+        if (s.w1 == s.w0) { own_first = total_end; own_end = total_end; }
+        const uint64_t need_end = s.w1 > s.w0 ? (s.w1 - 1) * step + rpw : own_first;
+        s.own_first = own_first;
+        s.own_count = own_end > own_first ? own_end - own_first : 0;
+        s.halo = need_end > own_end ? need_end - own_end : 0;
+    }
+}
+}  // namespace
+
+int qd_plan_create_ex(const qd_chain_desc *desc, const qd_plan_options *options, qd_plan **out) {
     if (!desc || !out) return fail(QD_ERR_INVALID, "desc/plan is NULL");
     if (desc->struct_size != sizeof(qd_chain_desc)) return fail(QD_ERR_INVALID, "qd_chain_desc size mismatch");
+    qd_plan_options opt{};
+    opt.struct_size = sizeof opt;
+    if (options) {
+        if (options->struct_size != sizeof(qd_plan_options)) return fail(QD_ERR_INVALID, "qd_plan_options size mismatch");
+        opt = *options;
+        if (opt.kernel_policy < QD_KERNEL_AUTO || opt.kernel_policy > QD_KERNEL_NO_PLAN_TIME) return fail(QD_ERR_INVALID, "unknown kernel_policy %d", opt.kernel_policy);
+        if (opt.nco_order < 0 || opt.nco_order > 2) return fail(QD_ERR_INVALID, "nco_order must be 0, 1 or 2");
+        if (opt.copy_threads > 64) return fail(QD_ERR_INVALID, "copy_threads > 64");
+        if (opt.chunk_bytes && (opt.chunk_bytes < (1u << 16) || opt.chunk_bytes > (1ull << 34))) return fail(QD_ERR_INVALID, "chunk_bytes outside [64 KiB, 16 GiB]");
+        if (opt.n_shards > QD_MAX_SHARDS) return fail(QD_ERR_INVALID, "n_shards > %d", QD_MAX_SHARDS);
+    }
     const qd_chain_desc &d = *desc;
     if (d.format < 0 || d.format > 3) return fail(QD_ERR_INVALID, "unknown format %d", d.format);
     if (d.epilogue < 0 || d.epilogue > 3) return fail(QD_ERR_INVALID, "unknown epilogue %d", d.epilogue);
@@ -860,24 +1000,53 @@ int qd_plan_create(const qd_chain_desc *desc, qd_plan **out) {
     }
     if (d.epilogue != QD_EPI_CF32_BLOCKS && len < d.width) return fail(QD_ERR_PANIC, "len %llu < width %llu: u64 underflow at src/fft.rs:28,86",
                                    (unsigned long long)len, (unsigned long long)d.width);
+    if (opt.n_shards > 1) {
+        int n_dev = 0;
+        HIPCHK(hipGetDeviceCount(&n_dev));
+        for (uint32_t g = 0; g < opt.n_shards; ++g)
+            if (opt.shard_device[g] < 0 || opt.shard_device[g] >= n_dev)
+                return fail(QD_ERR_INVALID, "shard %u: device %d does not exist (%d visible)", g, opt.shard_device[g], n_dev);
+    }
     qd_plan *p = new qd_plan();
     p->d = d;
+    p->opt = opt;
     int rc = plan_init(p, d, len, rate);
     if (rc) { qd_plan_destroy(p); return rc; }
+    // sharded plans: the parent describes the whole stream; each shard gets a plan of its own on its device
+    const uint32_t n_shards = opt.n_shards > 1 ? opt.n_shards : 1;
+    const uint64_t step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D, rpw = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
+    const uint32_t tile_api = p->blk_len ? 1u : p->geo.G;        // API windows of the write sink are whole blocks
+    partition_windows(p->n_windows, n_shards, step, rpw, tile_api, &p->shard_info);
+    for (uint32_t g = 0; g < n_shards; ++g) p->shard_info[g].device = n_shards > 1 ? opt.shard_device[g] : p->device;
+    if (n_shards > 1) {
+        qd_plan_options copt = opt;
+        copt.n_shards = 0;
+        for (uint32_t g = 0; g < n_shards && rc == QD_OK; ++g) {
+            DeviceGuard guard(opt.shard_device[g]);
+            qd_plan *c = nullptr;
+            rc = qd_plan_create_ex(desc, &copt, &c);
+            if (rc == QD_OK) p->shards.push_back(c);
+        }
+        if (rc) { qd_plan_destroy(p); return rc; }
+    }
     *out = p;
     return QD_OK;
 }
 
+int qd_plan_create(const qd_chain_desc *desc, qd_plan **out) { return qd_plan_create_ex(desc, nullptr, out); }
+
 int qd_plan_destroy(qd_plan *p) {
     if (!p) return QD_OK;
+    for (qd_plan *c : p->shards) (void)qd_plan_destroy(c);
+    p->shards.clear();
+    DeviceGuard guard(p->device);
     (void)hipDeviceSynchronize();
     free_streaming(p);
     if (p->taps_d) (void)hipFree(p->taps_d);
     if (p->tw_d) (void)hipFree(p->tw_d);
     if (p->jtab_d) (void)hipFree(p->jtab_d);
-    if (p->rowtab_d) (void)hipFree(p->rowtab_d);
     if (p->jtab256_d) (void)hipFree(p->jtab256_d);
-    if (p->rowtab256_d) (void)hipFree(p->rowtab256_d);
+    for (NcoTabs *t : {&p->tabs_dev, &p->tabs_slot[0], &p->tabs_slot[1]}) { free_rowtab(&t->main); free_rowtab(&t->tail); }
     if (p->ev_made) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
     delete p;
     return QD_OK;
@@ -932,14 +1101,12 @@ int qd_plan_last_kernel_ms(qd_plan *p, float *ms) {
 
 namespace {
 // Pageable -> pinned staging copy on several host threads: one thread moves ~10-15 GB/s, which would cap the
-// host-resident path far below PCIe; QD_COPY_THREADS overrides the thread count (default: up to 8).
-void par_memcpy(void *dst, const void *src, size_t n) {
-    static const unsigned n_thr = [] {
-        if (const char *e = getenv("QD_COPY_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) return (unsigned)v; }
+// host-resident path far below PCIe (qd_plan_options.copy_threads; default: up to 8).
+void par_memcpy(void *dst, const void *src, size_t n, unsigned n_thr) {
+    if (n_thr == 0) {
         unsigned hw = std::thread::hardware_concurrency();
-        unsigned t = hw / 2; if (t < 1) t = 1; if (t > 8) t = 8;
-        return t;
-    }();
+        n_thr = hw / 2; if (n_thr < 1) n_thr = 1; if (n_thr > 8) n_thr = 8;
+    }
     if (n_thr <= 1 || n < (8u << 20)) { memcpy(dst, src, n); return; }
     const size_t slice = ((n / n_thr) + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;
@@ -952,6 +1119,92 @@ void par_memcpy(void *dst, const void *src, size_t n) {
     memcpy(dst, src, slice < n ? slice : n);
     for (auto &t : th) t.join();
 }
+
+double now_ms() {
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+bool host_kind(int m) { return m == QD_MEM_HOST || m == QD_MEM_HOST_PINNED; }
+
+// Host-resident stream: chunked, double-buffered H2D / kernel / D2H on two streams (slot = chunk parity).  A pageable
+// buffer (QD_MEM_HOST) is staged through a pinned ring with a multi-threaded memcpy; QD_MEM_HOST_PINNED memory is the
+// DMA source / target itself.  Each slot owns its device buffers AND its NCO row table, so nothing a kernel in flight on
+// the other slot reads is ever touched.  Windows are kernel windows (sub-blocks for QD_EPI_CF32_BLOCKS).
+int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint64_t src_count, uint64_t first_window,
+             uint64_t n_windows, void *out, int out_mem, uint64_t obw) {
+    const double t_begin = now_ms();
+    p->stats = qd_plan_stats{};
+    const int bps = bps_of(p->d.format);
+    const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
+    const uint64_t target_bytes = p->opt.chunk_bytes ? p->opt.chunk_bytes : (64ull << 20);
+    uint64_t cw = target_bytes / (step * bps ? step * bps : 1);
+    if (cw < p->geo.G) cw = p->geo.G;
+    cw = (cw / p->geo.G) * p->geo.G;
+    if (cw > n_windows) cw = n_windows ? n_windows : 1;
+    const size_t in_bytes = (size_t)(((cw - 1) * step + rpw + 8) * bps), ob = (size_t)(cw * obw);
+    const bool stage_in = src_mem == QD_MEM_HOST, stage_out = out_mem == QD_MEM_HOST;
+    if (in_bytes > p->stage_in_bytes || ob > p->stage_out_bytes || (stage_in && in_bytes > p->pin_in_bytes) || (stage_out && ob > p->pin_out_bytes)) {
+        free_streaming(p);
+        for (int i = 0; i < 2; ++i) {
+            if (stage_in) HIPCHK(hipHostMalloc(&p->pin_in[i], in_bytes, hipHostMallocDefault));
+            if (stage_out) HIPCHK(hipHostMalloc(&p->pin_out[i], ob, hipHostMallocDefault));
+            HIPCHK(hipMalloc(&p->dev_in[i], in_bytes));
+            HIPCHK(hipMalloc(&p->dev_out[i], ob));
+            HIPCHK(hipStreamCreateWithFlags(&p->streams[i], hipStreamNonBlocking));
+        }
+        p->stage_in_bytes = in_bytes; p->stage_out_bytes = ob;
+        p->pin_in_bytes = stage_in ? in_bytes : 0; p->pin_out_bytes = stage_out ? ob : 0;
+    }
+    double stage_ms = 0;
+    struct Pending { bool live = false; uint64_t w0 = 0, nw = 0; } pend[2];
+    auto drain = [&](int slot) -> int {
+        if (!pend[slot].live) return QD_OK;
+        HIPCHK(hipStreamSynchronize(p->streams[slot]));
+        if (stage_out) {
+            const double t0 = now_ms();
+            par_memcpy(static_cast<uint8_t *>(out) + (pend[slot].w0 - first_window) * obw, p->pin_out[slot], pend[slot].nw * obw, p->opt.copy_threads);
+            stage_ms += now_ms() - t0;
+        }
+        pend[slot].live = false;
+        return QD_OK;
+    };
+    int slot = 0;
+    for (uint64_t w = first_window; w < first_window + n_windows; w += cw, slot ^= 1) {
+        // a staged slot's pinned buffers are reused: wait for its previous chunk; a pinned-to-pinned run only needs
+        // stream order (same slot = same stream), so the host runs ahead and just bounds the queue depth
+        int rc = (stage_in || stage_out || ((w - first_window) / cw) % 16 >= 14) ? drain(slot) : QD_OK;
+        if (rc) return rc;
+        const uint64_t nw = first_window + n_windows - w < cw ? first_window + n_windows - w : cw;
+        const uint64_t s0 = w * step, cnt = (nw - 1) * step + rpw;
+        // keep vector loads aligned: start the slab on a multiple of 8 samples
+        uint64_t s0a = s0 & ~7ull;
+        if (s0a < src_first) s0a = src_first;
+        const uint64_t cnta = s0 + cnt - s0a;
+        if (s0a < src_first || s0a + cnta > src_first + src_count)
+            return fail(QD_ERR_INVALID, "src slab does not cover the requested windows");
+        const uint8_t *hsrc = static_cast<const uint8_t *>(src) + (s0a - src_first) * bps;
+        if (stage_in) {
+            const double t0 = now_ms();
+            par_memcpy(p->pin_in[slot], hsrc, cnta * bps, p->opt.copy_threads);
+            stage_ms += now_ms() - t0;
+            hsrc = static_cast<const uint8_t *>(p->pin_in[slot]);
+        }
+        HIPCHK(hipMemcpyAsync(p->dev_in[slot], hsrc, cnta * bps, hipMemcpyHostToDevice, p->streams[slot]));
+        rc = launch_chain(p, &p->tabs_slot[slot], p->dev_in[slot], s0a, cnta, w, nw, w, p->dev_out[slot], p->streams[slot]);
+        if (rc) return rc;
+        void *hdst = stage_out ? p->pin_out[slot] : static_cast<void *>(static_cast<uint8_t *>(out) + (w - first_window) * obw);
+        HIPCHK(hipMemcpyAsync(hdst, p->dev_out[slot], nw * obw, hipMemcpyDeviceToHost, p->streams[slot]));
+        pend[slot].live = true; pend[slot].w0 = w; pend[slot].nw = nw;
+        p->stats.bytes_h2d += cnta * bps; p->stats.bytes_d2h += nw * obw; p->stats.chunks += 1;
+    }
+    int rc = drain(0);
+    if (rc) return rc;
+    rc = drain(1);
+    p->stats.stage_ms = stage_ms;
+    p->stats.wall_ms = now_ms() - t_begin;
+    return rc;
+}
 }  // namespace
 
 int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint64_t src_count,
@@ -963,120 +1216,393 @@ int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, ui
                     (unsigned long long)n_windows, (unsigned long long)p->n_windows);
     if (src_first + src_count > p->d.n_samples) return fail(QD_ERR_INVALID, "src slab exceeds the stream length");
     std::lock_guard<std::mutex> lock(p->mu);
+    DeviceGuard guard(p->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (src_mem == QD_MEM_DEVICE && out_mem == QD_MEM_DEVICE)
-        return launch_chain(p, src, src_first, src_count, first_window * subs, n_windows * subs, first_window * subs, out, st);
-    if (src_mem != QD_MEM_HOST || out_mem != QD_MEM_HOST)
+        return launch_chain(p, &p->tabs_dev, src, src_first, src_count, first_window * subs, n_windows * subs, first_window * subs, out, st);
+    if (!host_kind(src_mem) || !host_kind(out_mem))
         return fail(QD_ERR_UNSUPPORTED, "mixed host/device buffers are not supported; use both host or both device");
-
-    // host-resident stream: chunked, double-buffered H2D / kernel / D2H
-    const int bps = bps_of(p->d.format);
     const uint64_t obw = out_bytes_per_window(p) / subs;      // per kernel window (a sub-block for QD_EPI_CF32_BLOCKS)
-    first_window *= subs; n_windows *= subs;                  // from here on: kernel-window units
-    const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
-    uint64_t target_bytes = 64ull << 20;
-    if (const char *e = getenv("QD_CHUNK_MB")) { int v = atoi(e); if (v >= 1 && v <= 4096) target_bytes = (uint64_t)v << 20; }   // tuning knob
-    uint64_t cw = target_bytes / (step * bps ? step * bps : 1);
-    if (cw < p->geo.G) cw = p->geo.G;
-    cw = (cw / p->geo.G) * p->geo.G;
-    if (cw > n_windows) cw = n_windows ? n_windows : 1;
-    const size_t in_bytes = (size_t)(((cw - 1) * step + rpw + 8) * bps), ob = (size_t)(cw * obw);
-    if (in_bytes > p->stage_in_bytes || ob > p->stage_out_bytes) {
-        free_streaming(p);
-        for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipHostMalloc(&p->pin_in[i], in_bytes, hipHostMallocDefault));
-            HIPCHK(hipHostMalloc(&p->pin_out[i], ob, hipHostMallocDefault));
-            HIPCHK(hipMalloc(&p->dev_in[i], in_bytes));
-            HIPCHK(hipMalloc(&p->dev_out[i], ob));
-            HIPCHK(hipStreamCreateWithFlags(&p->streams[i], hipStreamNonBlocking));
-        }
-        p->stage_in_bytes = in_bytes; p->stage_out_bytes = ob;
-    }
-    struct Pending { bool live = false; uint64_t w0 = 0, nw = 0; } pend[2];
-    auto drain = [&](int slot) -> int {
-        if (!pend[slot].live) return QD_OK;
-        HIPCHK(hipStreamSynchronize(p->streams[slot]));
-        par_memcpy(static_cast<uint8_t *>(out) + (pend[slot].w0 - first_window) * obw, p->pin_out[slot], pend[slot].nw * obw);
-        pend[slot].live = false;
-        return QD_OK;
-    };
-    int slot = 0;
-    for (uint64_t w = first_window; w < first_window + n_windows; w += cw, slot ^= 1) {
-        int rc = drain(slot);
-        if (rc) return rc;
-        uint64_t nw = first_window + n_windows - w < cw ? first_window + n_windows - w : cw;
-        uint64_t s0 = w * step, cnt = (nw - 1) * step + rpw;
-        // keep vector loads aligned: start the slab on a multiple of 8 samples
-        uint64_t s0a = s0 & ~7ull;
-        if (s0a < src_first) s0a = src_first;
-        uint64_t cnta = s0 + cnt - s0a;
-        if (s0a < src_first || s0a + cnta > src_first + src_count)
-            return fail(QD_ERR_INVALID, "src slab does not cover the requested windows");
-        par_memcpy(p->pin_in[slot], static_cast<const uint8_t *>(src) + (s0a - src_first) * bps, cnta * bps);
-        HIPCHK(hipMemcpyAsync(p->dev_in[slot], p->pin_in[slot], cnta * bps, hipMemcpyHostToDevice, p->streams[slot]));
-        rc = launch_chain(p, p->dev_in[slot], s0a, cnta, w, nw, w, p->dev_out[slot], p->streams[slot]);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(p->pin_out[slot], p->dev_out[slot], nw * obw, hipMemcpyDeviceToHost, p->streams[slot]));
-        pend[slot].live = true; pend[slot].w0 = w; pend[slot].nw = nw;
-    }
-    int rc = drain(0);
-    if (rc) return rc;
-    return drain(1);
+    return run_host(p, src, src_mem, src_first, src_count, first_window * subs, n_windows * subs, out, out_mem, obw);
 }
 
+int qd_plan_get_stats(const qd_plan *p, qd_plan_stats *stats) {
+    if (!p || !stats) return fail(QD_ERR_INVALID, "NULL argument");
+    *stats = p->stats;
+    return QD_OK;
+}
+
+int qd_plan_shard_info(const qd_plan *p, uint32_t shard, qd_shard_info *info) {
+    if (!p || !info) return fail(QD_ERR_INVALID, "NULL argument");
+    if (shard >= p->shard_info.size()) return fail(QD_ERR_INVALID, "shard %u of %zu", shard, p->shard_info.size());
+    *info = p->shard_info[shard];
+    return QD_OK;
+}
+
+int qd_plan_run_sharded(qd_plan *p, const void *src, int src_mem, void *out, int out_mem) {
+    if (!p || !src || !out) return fail(QD_ERR_INVALID, "NULL argument");
+    if (!host_kind(src_mem) || !host_kind(out_mem)) return fail(QD_ERR_INVALID, "qd_plan_run_sharded takes host buffers (QD_MEM_HOST / QD_MEM_HOST_PINNED)");
+    if (p->shards.empty()) return qd_plan_run(p, src, src_mem, 0, p->d.n_samples, 0, p->n_windows, out, out_mem, nullptr);
+    // one host thread per shard: each drives its device's double-buffered ring; every shard reads its windows' source
+    // range — halo included — straight from the host buffer, so there is no exchange step at all
+    const uint64_t obw_api = out_bytes_per_window(p);
+    const size_t n = p->shards.size();
+    std::vector<int> rcs(n, QD_OK);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < n; ++g) {
+        th.emplace_back([&, g] {
+            const qd_shard_info &si = p->shard_info[g];
+            if (si.w1 == si.w0) return;
+            rcs[g] = qd_plan_run(p->shards[g], src, src_mem, 0, p->d.n_samples, si.w0, si.w1 - si.w0,
+                                 static_cast<uint8_t *>(out) + si.w0 * obw_api, out_mem, nullptr);
+            if (rcs[g]) errs[g] = g_err;         // thread-local message of the worker
+        });
+    }
+    for (auto &t : th) t.join();
+    p->stats = qd_plan_stats{};
+    for (size_t g = 0; g < n; ++g) {
+        if (rcs[g]) return fail(rcs[g], "shard %zu (device %d): %s", g, p->shard_info[g].device, errs[g].c_str());
+        const qd_plan_stats &cs = p->shards[g]->stats;
+        p->stats.wall_ms = std::max(p->stats.wall_ms, cs.wall_ms); p->stats.stage_ms += cs.stage_ms;
+        p->stats.bytes_h2d += cs.bytes_h2d; p->stats.bytes_d2h += cs.bytes_d2h; p->stats.chunks += cs.chunks;
+    }
+    return QD_OK;
+}
+
+int qd_plan_run_sharded_device(qd_plan *p, void *const *slabs, void *const *outs, int sync) {
+    if (!p || !slabs || !outs) return fail(QD_ERR_INVALID, "NULL argument");
+    const size_t n = p->shard_info.size();
+    const int bps = bps_of(p->d.format);
+    std::vector<qd_plan *> plans(n, p);
+    for (size_t g = 0; g < n && !p->shards.empty(); ++g) plans[g] = p->shards[g];
+    for (size_t g = 0; g < n; ++g) {
+        const qd_shard_info &si = p->shard_info[g];
+        if (si.w1 == si.w0) continue;
+        if (!slabs[g] || !outs[g]) return fail(QD_ERR_INVALID, "shard %zu: NULL slab / out", g);
+        if (si.halo && (g + 1 >= n || p->shard_info[g + 1].own_count < si.halo))
+            return fail(QD_ERR_INVALID, "shard %zu needs a %llu-sample halo its neighbour does not own: use fewer shards", g, (unsigned long long)si.halo);
+    }
+    for (size_t g = 0; g < n; ++g) {
+        const qd_shard_info &si = p->shard_info[g];
+        if (si.w1 == si.w0) continue;
+        qd_plan *c = plans[g];
+        std::lock_guard<std::mutex> lock(c->mu);
+        DeviceGuard guard(si.device);
+        if (!c->streams[0]) HIPCHK(hipStreamCreateWithFlags(&c->streams[0], hipStreamNonBlocking));
+        if (si.halo)     // the one exchange step of a pre-split device-resident stream: (W-S)*D+T samples from the next slab
+            HIPCHK(hipMemcpyPeerAsync(static_cast<uint8_t *>(slabs[g]) + si.own_count * bps, si.device, slabs[g + 1],
+                                      p->shard_info[g + 1].device, si.halo * bps, c->streams[0]));
+        const uint64_t subs = c->blk_subs;
+        int rc = launch_chain(c, &c->tabs_dev, slabs[g], si.own_first, si.own_count + si.halo, si.w0 * subs, (si.w1 - si.w0) * subs,
+                              si.w0 * subs, outs[g], c->streams[0]);
+        if (rc) return rc;
+    }
+    if (sync) {
+        for (size_t g = 0; g < n; ++g) {
+            if (p->shard_info[g].w1 == p->shard_info[g].w0 || !plans[g]->streams[0]) continue;
+            DeviceGuard guard(p->shard_info[g].device);
+            HIPCHK(hipStreamSynchronize(plans[g]->streams[0]));
+        }
+    }
+    return QD_OK;
+}
+
+int qd_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return fail(QD_ERR_INVALID, "NULL argument");
+    *ptr = nullptr;
+    if (bytes == 0) return QD_OK;
+    HIPCHK(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return QD_OK;
+}
+int qd_host_free(void *ptr) { if (ptr) HIPCHK(hipHostFree(ptr)); return QD_OK; }
+int qd_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(QD_ERR_INVALID, "NULL / empty range");
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return QD_OK;
+}
+int qd_host_unregister(void *ptr) { if (ptr) HIPCHK(hipHostUnregister(ptr)); return QD_OK; }
+
 // ------------------------------------------------------------------ fine-grained ops
+//
+// These mirror one `read_at` each, so a host may call them once per window: no hipMalloc /
+// hipFree / plan construction per call.  Device temporaries come from a process-wide pool of grow-only workspaces; a
+// workspace is handed to one call at a time and remembers the stream that used it last, so reuse on the same stream
+// needs no synchronisation (stream order) and reuse on another stream waits for the old one first.  The FFT-based
+// calls keep their plans in a small cache.  All launches go to the calling thread's stream (qd_set_stream).
 
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+
+thread_local hipStream_t g_stream = nullptr;
+
+struct Workspace {
+    static constexpr int kSlots = 6;
+    void *buf[kSlots] = {};
+    size_t cap[kSlots] = {};
+    int device = 0;
+    hipStream_t last = nullptr;
+    bool used = false;
+    int get(int i, size_t bytes, void **out) {
+        if (bytes > cap[i]) {
+            if (buf[i]) {
+                if (used) HIPCHK(hipStreamSynchronize(last));
+                HIPCHK(hipFree(buf[i]));
+                buf[i] = nullptr; cap[i] = 0;
+            }
+            const size_t want = (bytes + bytes / 4 + 4095) & ~(size_t)4095;
+            HIPCHK(hipMalloc(&buf[i], want));
+            cap[i] = want;
+        }
+        *out = buf[i];
+        return QD_OK;
+    }
+    void release_buffers() {
+        for (int i = 0; i < kSlots; ++i) { if (buf[i]) (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+    }
 };
+
+std::mutex g_ws_mu;
+std::vector<Workspace *> g_ws_idle;
+
+struct WsLease {                        // one workspace for the duration of a call
+    Workspace *ws = nullptr;
+    int rc = QD_OK;
+    explicit WsLease(hipStream_t st) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lock(g_ws_mu);
+            size_t pick = g_ws_idle.size();
+            for (size_t i = 0; i < g_ws_idle.size(); ++i) {
+                if (g_ws_idle[i]->device != dev) continue;
+                if (pick == g_ws_idle.size() || g_ws_idle[i]->last == st) pick = i;
+                if (g_ws_idle[i]->last == st) break;
+            }
+            if (pick < g_ws_idle.size()) { ws = g_ws_idle[pick]; g_ws_idle.erase(g_ws_idle.begin() + pick); }
+        }
+        if (!ws) { ws = new Workspace(); ws->device = dev; }
+        if (ws->used && ws->last != st && hipStreamSynchronize(ws->last) != hipSuccess) rc = fail(QD_ERR_HIP, "workspace hand-over: stream synchronise failed");
+        ws->last = st; ws->used = true;
+    }
+    ~WsLease() { std::lock_guard<std::mutex> lock(g_ws_mu); g_ws_idle.push_back(ws); }
+    int get(int i, size_t bytes, void **out) { return ws->get(i, bytes, out); }
+};
+
+// plans of the FFT-based fine-grained calls, keyed by (device, width, stride, kind)
+struct CachedPlan { int device; uint64_t W, S; int kind; qd_plan *plan; std::mutex mu; };
+std::mutex g_pc_mu;
+std::vector<CachedPlan *> g_plan_cache;
+constexpr size_t kPlanCacheMax = 32;
+constexpr uint64_t kOpenEnded = 1ull << 40;      // "any number of windows": the cached plans size no loop from it
+
+int cached_fft_plan(uint64_t W, uint64_t S, int kind, CachedPlan **out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    for (CachedPlan *c : g_plan_cache)
+        if (c->device == dev && c->W == W && c->S == S && c->kind == kind) { *out = c; return QD_OK; }
+    qd_chain_desc d{};
+    d.struct_size = sizeof d;
+    d.format = QD_FMT_CF32; d.sample_rate = 1;
+    d.n_samples = kOpenEnded;
+    d.width = W; d.stride = S; d.epilogue = QD_EPI_NORMS_F32;
+    qd_plan_options o{};
+    o.struct_size = sizeof o;
+    o.kernel_policy = QD_KERNEL_NO_PLAN_TIME;      // a per-window helper must not stall on a compile
+    qd_plan *p = nullptr;
+    int rc = qd_plan_create_ex(&d, &o, &p);
+    if (rc) return rc;
+    if (kind == 1) {                               // take_fft: one irregular row per tile, per-sample (unaligned) kernel
+        p->geo.G = 1;
+        uint32_t raw_elems = 0;
+        p->geo.lds_bytes = lds_for(1, p->W, p->S, p->D, p->T, &raw_elems);
+        p->geo.lds_raw_elems = raw_elems;
+        p->fn = p->fn_unaligned;
+    }
+    if (g_plan_cache.size() >= kPlanCacheMax) {    // evict the oldest entry nobody is using
+        for (size_t i = 0; i < g_plan_cache.size(); ++i) {
+            if (g_plan_cache[i]->mu.try_lock()) {
+                CachedPlan *victim = g_plan_cache[i];
+                g_plan_cache.erase(g_plan_cache.begin() + i);
+                victim->mu.unlock();
+                (void)qd_plan_destroy(victim->plan);
+                delete victim;
+                break;
+            }
+        }
+    }
+    CachedPlan *c = new CachedPlan{dev, W, S, kind, p, {}};
+    g_plan_cache.push_back(c);
+    *out = c;
+    return QD_OK;
+}
+
+// ---- Bluestein tables per width (host f64 arithmetic, rounded once to f32), cached per device
+struct BluesteinTab { int device; uint32_t W, M, logM; float2 *chirp, *Bbr, *tw; };
+std::mutex g_bt_mu;
+std::vector<BluesteinTab> g_bt;
+
+void fft64_inplace(std::vector<double> &re, std::vector<double> &im, uint32_t logM) {   // radix-2 DIT, natural order out
+    const uint32_t M = 1u << logM;
+    for (uint32_t i = 0; i < M; ++i) {
+        uint32_t r = 0;
+        for (uint32_t b = 0; b < logM; ++b) if (i & (1u << b)) r |= 1u << (logM - 1 - b);
+        if (r > i) { std::swap(re[i], re[r]); std::swap(im[i], im[r]); }
+    }
+    for (uint32_t h = 1; h < M; h <<= 1) {
+        for (uint32_t j = 0; j < h; ++j) {
+            const double ang = -kPi64 * (double)j / (double)h, wr = std::cos(ang), wi = std::sin(ang);
+            for (uint32_t i = j; i < M; i += 2 * h) {
+                const double vr = re[i + h] * wr - im[i + h] * wi, vi = re[i + h] * wi + im[i + h] * wr;
+                re[i + h] = re[i] - vr; im[i + h] = im[i] - vi;
+                re[i] += vr; im[i] += vi;
+            }
+        }
+    }
+}
+
+int bluestein_tab(uint32_t W, BluesteinTab *out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_bt_mu);
+    for (const BluesteinTab &t : g_bt) if (t.device == dev && t.W == W) { *out = t; return QD_OK; }
+    BluesteinTab t{};
+    t.device = dev; t.W = W;
+    t.logM = ilog2(2ull * W - 1); t.M = 1u << t.logM;
+    const uint32_t M = t.M;
+    std::vector<float2> chirp(W), Bbr(M), tw(M / 2 ? M / 2 : 1);
+    std::vector<double> br(M, 0.0), bi(M, 0.0);
+    for (uint32_t n = 0; n < W; ++n) {
+        const uint64_t q = ((uint64_t)n * n) % (2ull * W);       // n^2 mod 2W: the angle is reduced exactly, in integers
+        const double ang = kPi64 * (double)q / (double)W;
+        const double cr = std::cos(ang), ci = std::sin(ang);     // b[n] = e^{+i pi n^2 / W}
+        chirp[n] = make_float2((float)cr, (float)-ci);            // c[n] = conj(b[n])
+        br[n] = cr; bi[n] = ci;
+        if (n) { br[M - n] = cr; bi[M - n] = ci; }
+    }
+    fft64_inplace(br, bi, t.logM);
+    for (uint32_t r = 0; r < M; ++r) {
+        uint32_t k = 0;
+        for (uint32_t b = 0; b < t.logM; ++b) if (r & (1u << b)) k |= 1u << (t.logM - 1 - b);
+        Bbr[r] = make_float2((float)(br[k] / (double)M), (float)(bi[k] / (double)M));
+    }
+    for (uint32_t k = 0; k < M / 2; ++k) {
+        const double ang = -2.0 * kPi64 * (double)k / (double)M;
+        tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    if (M / 2 == 0) tw[0] = make_float2(1.f, 0.f);
+    HIPCHK(hipMalloc(&t.chirp, chirp.size() * 8)); HIPCHK(hipMalloc(&t.Bbr, Bbr.size() * 8)); HIPCHK(hipMalloc(&t.tw, tw.size() * 8));
+    HIPCHK(hipMemcpy(t.chirp, chirp.data(), chirp.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.Bbr, Bbr.data(), Bbr.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    if (g_bt.size() >= 64) {                                      // the width slider walks through many lengths: bound the cache
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_bt[0].chirp); (void)hipFree(g_bt[0].Bbr); (void)hipFree(g_bt[0].tw);
+        g_bt.erase(g_bt.begin());
+    }
+    g_bt.push_back(t);
+    *out = t;
+    return QD_OK;
+}
+
+int bluestein_rows(const float2 *src, uint64_t in_first, const uint64_t *offs_d, const float *win_d, size_t W, size_t n_rows,
+                   float *dst, hipStream_t st) {
+    if (W > 8192) return fail(QD_ERR_UNSUPPORTED, "take_fft width %zu: widths that are not a power of two are built up to 8192", W);
+    BluesteinTab t{};
+    int rc = bluestein_tab((uint32_t)W, &t);
+    if (rc) return rc;
+    if ((size_t)t.M * 8 > 48 * 1024)      // per device, cheap: raise the dynamic-LDS limit to the hardware maximum
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bluestein), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    hipLaunchKernelGGL(k_bluestein, dim3((uint32_t)n_rows), dim3(256), (size_t)t.M * 8, st, src, in_first, offs_d, win_d, (uint32_t)W, t.M, t.logM,
+                       t.chirp, t.Bbr, t.tw, dst);
+    HIPCHK(hipGetLastError());
+    return QD_OK;
+}
+
+int finish_call(int mem, hipStream_t st) {         // host buffers: results must be there on return
+    if (mem != QD_MEM_DEVICE) HIPCHK(hipStreamSynchronize(st));
+    return QD_OK;
+}
+
 }  // namespace
+
+int qd_set_stream(void *stream) { g_stream = static_cast<hipStream_t>(stream); return QD_OK; }
+
+int qd_release_workspaces(void) {
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        for (Workspace *w : g_ws_idle) {
+            DeviceGuard guard(w->device);
+            if (w->used) (void)hipStreamSynchronize(w->last);
+            w->release_buffers();
+            delete w;
+        }
+        g_ws_idle.clear();
+    }
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    for (size_t i = 0; i < g_plan_cache.size();) {
+        if (g_plan_cache[i]->mu.try_lock()) {
+            CachedPlan *c = g_plan_cache[i];
+            g_plan_cache.erase(g_plan_cache.begin() + i);
+            c->mu.unlock();
+            (void)qd_plan_destroy(c->plan);
+            delete c;
+        } else ++i;
+    }
+    return QD_OK;
+}
 
 int qd_unpack(int fmt, const void *bytes, size_t n_pairs, qd_c32 *out, int mem) {
     if (fmt < 0 || fmt > 3) return fail(QD_ERR_INVALID, "unknown format %d", fmt);
     if (n_pairs == 0) return QD_OK;
     if (!bytes || !out) return fail(QD_ERR_INVALID, "NULL buffer");
     const size_t ib = n_pairs * qd_pair_bytes(fmt), ob = n_pairs * 8;
-    DevBuf di, dout;
+    const hipStream_t st = g_stream;
+    WsLease ws(st);
+    if (ws.rc) return ws.rc;
     const void *src = bytes; void *dst = out;
-    if (mem == QD_MEM_HOST) {
-        HIPCHK(hipMalloc(&di.p, ib)); HIPCHK(hipMalloc(&dout.p, ob));
-        HIPCHK(hipMemcpy(di.p, bytes, ib, hipMemcpyHostToDevice));
-        src = di.p; dst = dout.p;
+    if (mem != QD_MEM_DEVICE) {
+        void *di = nullptr, *dout = nullptr;
+        int rc = ws.get(0, ib, &di); if (rc) return rc;
+        rc = ws.get(1, ob, &dout); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(di, bytes, ib, hipMemcpyHostToDevice, st));
+        src = di; dst = dout;
     }
     size_t blocks = (n_pairs + 255) / 256; if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_unpack, dim3((uint32_t)blocks), dim3(256), 0, 0, fmt, static_cast<const uint8_t *>(src), n_pairs,
+    hipLaunchKernelGGL(k_unpack, dim3((uint32_t)blocks), dim3(256), 0, st, fmt, static_cast<const uint8_t *>(src), n_pairs,
                        static_cast<float2 *>(dst));
     HIPCHK(hipGetLastError());
-    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
-    return QD_OK;
+    if (mem != QD_MEM_DEVICE) HIPCHK(hipMemcpyAsync(out, dst, ob, hipMemcpyDeviceToHost, st));
+    return finish_call(mem, st);
 }
 
 int qd_shift(qd_c32 *buf, size_t n, uint64_t abs_off, double ratio, int mem) {
     if (n == 0) return QD_OK;
     if (!buf) return fail(QD_ERR_INVALID, "NULL buffer");
     constexpr uint32_t ROW = 512;
-    DevBuf db, rt, jt;
+    const hipStream_t st = g_stream;
+    WsLease ws(st);
+    if (ws.rc) return ws.rc;
     float2 *d = reinterpret_cast<float2 *>(buf);
-    if (mem == QD_MEM_HOST) {
-        HIPCHK(hipMalloc(&db.p, n * 8));
-        HIPCHK(hipMemcpy(db.p, buf, n * 8, hipMemcpyHostToDevice));
-        d = static_cast<float2 *>(db.p);
+    if (mem != QD_MEM_DEVICE) {
+        void *db = nullptr;
+        int rc = ws.get(0, n * 8, &db); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(db, buf, n * 8, hipMemcpyHostToDevice, st));
+        d = static_cast<float2 *>(db);
     }
-    uint64_t r0 = abs_off / ROW, r1 = (abs_off + n + ROW - 1) / ROW, rows = r1 - r0;
-    HIPCHK(hipMalloc(&rt.p, rows * sizeof(RowBase)));
-    HIPCHK(hipMalloc(&jt.p, ROW * sizeof(double2)));
-    hipLaunchKernelGGL(k_rowtab, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, 0, ratio, ROW, r0, rows, static_cast<RowBase *>(rt.p));
-    hipLaunchKernelGGL(k_jtab, dim3(2), dim3(256), 0, 0, ratio, ROW, static_cast<double2 *>(jt.p));
-    int so = (std::fabs(ratio) * (double)(abs_off + n) > 134217728.0) ? 1 : 0;
-    uint32_t grid = (uint32_t)(rows < 4096 ? rows : 4096);
-    hipLaunchKernelGGL(k_shift, dim3(grid), dim3(256), 0, 0, d, abs_off, (uint64_t)n, ratio, static_cast<const RowBase *>(rt.p), r0, rows,
-                       static_cast<const double2 *>(jt.p), so);
+    const uint64_t r0 = abs_off / ROW, r1 = (abs_off + n + ROW - 1) / ROW, rows = r1 - r0;
+    void *rt = nullptr, *jt = nullptr;
+    int rc = ws.get(2, rows * sizeof(RowBase), &rt); if (rc) return rc;
+    rc = ws.get(3, ROW * sizeof(double2), &jt); if (rc) return rc;
+    hipLaunchKernelGGL(k_rowtab, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, st, ratio, ROW, r0, rows, static_cast<RowBase *>(rt));
+    hipLaunchKernelGGL(k_jtab, dim3(2), dim3(256), 0, st, ratio, ROW, static_cast<double2 *>(jt));
+    const int so = (std::fabs(ratio) * (double)(abs_off + n) > 134217728.0) ? 1 : 0;
+    const uint32_t grid = (uint32_t)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL(k_shift, dim3(grid), dim3(256), 0, st, d, abs_off, (uint64_t)n, ratio, static_cast<const RowBase *>(rt), r0, rows,
+                       static_cast<const double2 *>(jt), so);
     HIPCHK(hipGetLastError());
-    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(buf, db.p, n * 8, hipMemcpyDeviceToHost));
-    else HIPCHK(hipDeviceSynchronize());   // tables are freed on return
-    return QD_OK;
+    if (mem != QD_MEM_DEVICE) HIPCHK(hipMemcpyAsync(buf, d, n * 8, hipMemcpyDeviceToHost, st));
+    return finish_call(mem, st);
 }
 
 int qd_lowpass_block(const float *taps, size_t T, uint64_t D, const qd_c32 *raw, size_t valid, qd_c32 *out,
@@ -1088,49 +1614,63 @@ int qd_lowpass_block(const float *taps, size_t T, uint64_t D, const qd_c32 *raw,
     if (out_n > out_cap) return fail(QD_ERR_PANIC, "buf too small for %zu outputs (src/filter.rs:78-80)", out_n);
     *produced = out_n;
     if (out_n == 0) return QD_OK;
-    DevBuf dt, dr, dout;
-    HIPCHK(hipMalloc(&dt.p, T * 4));
-    HIPCHK(hipMemcpy(dt.p, taps, T * 4, hipMemcpyHostToDevice));   // taps are always host (O(T))
+    const hipStream_t st = g_stream;
+    WsLease ws(st);
+    if (ws.rc) return ws.rc;
+    void *dt = nullptr;
+    int rc = ws.get(2, T * 4, &dt); if (rc) return rc;
+    // taps are always host memory (O(T)); the caller may reuse its array at once, so this small copy is synchronous
+    HIPCHK(hipMemcpyAsync(dt, taps, T * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
     const float2 *r = reinterpret_cast<const float2 *>(raw);
     float2 *o = reinterpret_cast<float2 *>(out);
-    if (mem == QD_MEM_HOST) {
-        HIPCHK(hipMalloc(&dr.p, valid * 8)); HIPCHK(hipMalloc(&dout.p, out_n * 8));
-        HIPCHK(hipMemcpy(dr.p, raw, valid * 8, hipMemcpyHostToDevice));
-        r = static_cast<const float2 *>(dr.p); o = static_cast<float2 *>(dout.p);
+    if (mem != QD_MEM_DEVICE) {
+        void *dr = nullptr, *dout = nullptr;
+        rc = ws.get(0, valid * 8, &dr); if (rc) return rc;
+        rc = ws.get(1, out_n * 8, &dout); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(dr, raw, valid * 8, hipMemcpyHostToDevice, st));
+        r = static_cast<const float2 *>(dr); o = static_cast<float2 *>(dout);
     }
     size_t blocks = (out_n + 127) / 128; if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_lowpass_block, dim3((uint32_t)blocks), dim3(128), 0, 0, static_cast<const float *>(dt.p), (uint32_t)T, D, r,
+    hipLaunchKernelGGL(k_lowpass_block, dim3((uint32_t)blocks), dim3(128), 0, st, static_cast<const float *>(dt), (uint32_t)T, D, r,
                        (uint64_t)valid, o, (uint64_t)out_n);
     HIPCHK(hipGetLastError());
-    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(out, dout.p, out_n * 8, hipMemcpyDeviceToHost));
-    else HIPCHK(hipDeviceSynchronize());
-    return QD_OK;
+    if (mem != QD_MEM_DEVICE) HIPCHK(hipMemcpyAsync(out, o, out_n * 8, hipMemcpyDeviceToHost, st));
+    return finish_call(mem, st);
 }
 
 int qd_fft_norm_batch(const qd_c32 *in, size_t W, size_t n_fft, size_t in_stride, float *norms, int mem) {
     if (n_fft == 0) return QD_OK;
     if (!in || !norms) return fail(QD_ERR_INVALID, "NULL buffer");
     if (in_stride == 0) return fail(QD_ERR_INVALID, "in_stride 0");
-    qd_chain_desc d{};
-    d.struct_size = sizeof d;
-    d.format = QD_FMT_CF32; d.sample_rate = 1;
-    d.n_samples = (n_fft - 1) * in_stride + W + 1;     // so that the strict `<` loop yields n_fft windows
-    d.width = W; d.stride = in_stride; d.epilogue = QD_EPI_NORMS_F32;
-    // the window loop `i < len - W` needs len - W > (n_fft-1)*stride: len = (n_fft-1)*stride + W + 1
-    qd_plan *p = nullptr;
-    int rc = qd_plan_create(&d, &p);
+    if (!is_pow2(W)) return fail(QD_ERR_PANIC, "Radix4 requires a power-of-two width (rustfft API contract), got %zu", W);
+    CachedPlan *c = nullptr;
+    int rc = cached_fft_plan(W, in_stride, 0, &c);
     if (rc) return rc;
-    uint64_t have = (n_fft - 1) * in_stride + W;
-    rc = qd_plan_run(p, in, mem, 0, have, 0, n_fft, norms, mem, nullptr);
-    if (rc == QD_OK && mem == QD_MEM_DEVICE) { if (hipDeviceSynchronize() != hipSuccess) rc = fail(QD_ERR_HIP, "sync failed"); }
-    qd_plan_destroy(p);
-    return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    qd_plan *p = c->plan;
+    const hipStream_t st = g_stream;
+    WsLease ws(st);
+    if (ws.rc) return ws.rc;
+    const uint64_t have = (uint64_t)(n_fft - 1) * in_stride + W;
+    const void *src = in; void *dst = norms;
+    if (mem != QD_MEM_DEVICE) {
+        void *di = nullptr, *dout = nullptr;
+        rc = ws.get(0, have * 8, &di); if (rc) return rc;
+        rc = ws.get(1, n_fft * W * 4, &dout); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(di, in, have * 8, hipMemcpyHostToDevice, st));
+        src = di; dst = dout;
+    }
+    rc = launch_chain(p, &p->tabs_dev, src, 0, have, 0, n_fft, 0, dst, st);
+    if (rc) return rc;
+    if (mem != QD_MEM_DEVICE) HIPCHK(hipMemcpyAsync(norms, dst, n_fft * W * 4, hipMemcpyDeviceToHost, st));
+    return finish_call(mem, st);
 }
 
 int qd_take_fft(const qd_c32 *in, uint64_t in_first, size_t n_in, uint64_t samples_len, int has_slice,
                 uint64_t start, uint64_t end, size_t W, int windowing, size_t output_len, float *rows, int mem) {
     if (!in || !rows) return fail(QD_ERR_INVALID, "NULL buffer");
-    if (!is_pow2(W)) return fail(QD_ERR_UNSUPPORTED, "take_fft width %zu: only power-of-two widths are built (the reference's planner takes any)", W);
+    if (W < 1 || W > (1u << 20)) return fail(QD_ERR_UNSUPPORTED, "take_fft width %zu", W);
     if (!has_slice) {                                                             // src/ffts.rs:27-30
         if (samples_len < W) return fail(QD_ERR_PANIC, "len < width underflows (src/ffts.rs:29)");
         start = 0; end = samples_len - W;
@@ -1159,43 +1699,45 @@ int qd_take_fft(const qd_c32 *in, uint64_t in_first, size_t n_in, uint64_t sampl
             win[i] = 0.35875f - 0.48829f * std::cos(x) + 0.14128f * std::cos(2.0f * x) - 0.01168f * std::cos(3.0f * x);
         }
     }
-    qd_chain_desc d{};
-    d.struct_size = sizeof d;
-    d.format = QD_FMT_CF32; d.sample_rate = 1;
-    d.n_samples = (uint64_t)output_len * W + 1;        // only sizes the sink loop: output_len windows at stride W
-    d.width = W; d.stride = W; d.epilogue = QD_EPI_NORMS_F32;
-    qd_plan *p = nullptr;
-    int rc = qd_plan_create(&d, &p);
-    if (rc) return rc;
-    DevBuf doffs, dwin, din, dout;
-    auto cleanup = [&](int r) { qd_plan_destroy(p); return r; };
-    p->geo.G = 1;                                       // one irregular row per tile
-    {
-        uint32_t raw_elems = 0;
-        p->geo.lds_bytes = lds_for(1, p->W, p->S, p->D, p->T, &raw_elems);
-        p->geo.lds_raw_elems = raw_elems;
-    }
-    if (hipMalloc(&doffs.p, output_len * 8) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "hipMalloc offsets"));
-    if (hipMemcpy(doffs.p, offs.data(), output_len * 8, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "copy offsets"));
-    p->row_offsets_d = static_cast<const uint64_t *>(doffs.p);
+    const hipStream_t st = g_stream;
+    WsLease ws(st);
+    if (ws.rc) return ws.rc;
+    void *doffs = nullptr, *dwin = nullptr;
+    int rc = ws.get(2, output_len * 8, &doffs); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(doffs, offs.data(), output_len * 8, hipMemcpyHostToDevice, st));
     if (!win.empty()) {
-        if (hipMalloc(&dwin.p, W * 4) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "hipMalloc window"));
-        if (hipMemcpy(dwin.p, win.data(), W * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "copy window"));
-        p->window_d = static_cast<const float *>(dwin.p);
+        rc = ws.get(3, W * 4, &dwin); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(dwin, win.data(), W * 4, hipMemcpyHostToDevice, st));
     }
+    HIPCHK(hipStreamSynchronize(st));               // offs / win are locals of this call
     const void *src = in; void *dst = rows;
-    if (mem == QD_MEM_HOST) {
-        if (hipMalloc(&din.p, n_in * 8) != hipSuccess || hipMalloc(&dout.p, output_len * W * 4) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "hipMalloc"));
-        if (hipMemcpy(din.p, in, n_in * 8, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(QD_ERR_HIP, "H2D"));
-        src = din.p; dst = dout.p;
+    if (mem != QD_MEM_DEVICE) {
+        void *di = nullptr, *dout = nullptr;
+        rc = ws.get(0, n_in * 8, &di); if (rc) return rc;
+        rc = ws.get(1, output_len * W * 4, &dout); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(di, in, n_in * 8, hipMemcpyHostToDevice, st));
+        src = di; dst = dout;
     }
-    // rows are irregular: the per-sample kernel (no vector-alignment assumptions) reads them
-    p->fn = p->fn_unaligned;
-    p->d.n_samples = in_first + n_in;
-    rc = launch_chain(p, src, in_first, n_in, 0, output_len, 0, dst, nullptr);
-    if (rc == QD_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(QD_ERR_HIP, "sync failed");
-    if (rc == QD_OK && mem == QD_MEM_HOST && hipMemcpy(rows, dout.p, output_len * W * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(QD_ERR_HIP, "D2H");
-    return cleanup(rc);
+    if (is_pow2(W)) {
+        // rustfft's planner gives a power-of-two length to its Radix4 as well: the chain kernel's FFT (bit-exact against
+        // the oracle's restatement), rows gathered at irregular offsets by the per-sample kernel
+        CachedPlan *c = nullptr;
+        rc = cached_fft_plan(W, W, 1, &c);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lock(c->mu);
+        qd_plan *p = c->plan;
+        p->row_offsets_d = static_cast<const uint64_t *>(doffs);
+        p->window_d = static_cast<const float *>(dwin);
+        p->d.n_samples = in_first + n_in;
+        rc = launch_chain(p, &p->tabs_dev, src, in_first, n_in, 0, output_len, 0, dst, st);
+        p->row_offsets_d = nullptr; p->window_d = nullptr;
+    } else {
+        rc = bluestein_rows(static_cast<const float2 *>(src), in_first, static_cast<const uint64_t *>(doffs), static_cast<const float *>(dwin),
+                            W, output_len, static_cast<float *>(dst), st);
+    }
+    if (rc) return rc;
+    if (mem != QD_MEM_DEVICE) HIPCHK(hipMemcpyAsync(rows, dst, output_len * W * 4, hipMemcpyDeviceToHost, st));
+    return finish_call(mem, st);
 }
 
 int qd_device_alloc(size_t bytes, void **ptr) {
@@ -1227,17 +1769,20 @@ int qd_gen(const int64_t *cos_hz, size_t n_cos, uint64_t sample_rate, uint64_t f
     if (sample_rate == 0) return fail(QD_ERR_INVALID, "sample rate may not be zero (src/gen.rs:19)");
     if (n == 0) return QD_OK;
     if (!out) return fail(QD_ERR_INVALID, "NULL buffer");
-    DevBuf dc, dout;
-    HIPCHK(hipMalloc(&dc.p, n_cos * 8));
-    HIPCHK(hipMemcpy(dc.p, cos_hz, n_cos * 8, hipMemcpyHostToDevice));
+    const hipStream_t st = g_stream;
+    WsLease ws(st);
+    if (ws.rc) return ws.rc;
+    void *dc = nullptr;
+    int rc = ws.get(2, n_cos * 8, &dc); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(dc, cos_hz, n_cos * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));              // the tone list is the caller's array
     float2 *o = reinterpret_cast<float2 *>(out);
-    if (mem == QD_MEM_HOST) { HIPCHK(hipMalloc(&dout.p, n * 8)); o = static_cast<float2 *>(dout.p); }
+    if (mem != QD_MEM_DEVICE) { void *dout = nullptr; rc = ws.get(1, n * 8, &dout); if (rc) return rc; o = static_cast<float2 *>(dout); }
     size_t blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_gen, dim3((uint32_t)blocks), dim3(256), 0, 0, static_cast<const int64_t *>(dc.p), (uint32_t)n_cos, sample_rate, first, n, o);
+    hipLaunchKernelGGL(k_gen, dim3((uint32_t)blocks), dim3(256), 0, st, static_cast<const int64_t *>(dc), (uint32_t)n_cos, sample_rate, first, n, o);
     HIPCHK(hipGetLastError());
-    if (mem == QD_MEM_HOST) HIPCHK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
-    else HIPCHK(hipDeviceSynchronize());
-    return QD_OK;
+    if (mem != QD_MEM_DEVICE) HIPCHK(hipMemcpyAsync(out, o, n * 8, hipMemcpyDeviceToHost, st));
+    return finish_call(mem, st);
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@ Host numpy arrays go through the QD_MEM_HOST paths; torch CUDA tensors are passe
 (QD_MEM_DEVICE) on torch's current stream.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -106,11 +107,73 @@ def take_fft(x, width, output_len, slice_=None, windowing=1, in_first=0, samples
     return rows
 
 
+def plan_options(kernel_policy=_ffi.KERNEL_AUTO, nco_order=0, copy_threads=0, chunk_bytes=0, shard_devices=None, tile_hint=None):
+    """qd_plan_options (include/quadrs_hip.h): how a plan picks its kernel and moves host-resident streams."""
+    o = _ffi.PlanOptions()
+    o.struct_size = C.sizeof(_ffi.PlanOptions)
+    o.kernel_policy, o.nco_order, o.copy_threads, o.chunk_bytes = kernel_policy, nco_order, copy_threads, chunk_bytes
+    if shard_devices:
+        o.n_shards = len(shard_devices)
+        for i, d in enumerate(shard_devices):
+            o.shard_device[i] = d
+    if tile_hint:
+        for i, v in enumerate(tile_hint):
+            o.tile_hint[i] = int(v)
+    return o
+
+
+def options_from_env(**overrides):
+    """Harness convenience (tests, bench.py, scripts/): the library itself reads no tuning environment variables, so the
+    knobs the test matrix is run under are translated HERE into an explicit qd_plan_options —
+    QD_NO_FIXED=1 -> QD_KERNEL_GENERIC, QD_JIT=1 / 0 -> QD_KERNEL_SPECIALISE / QD_KERNEL_NO_PLAN_TIME,
+    QD_TUNE=G:NT:FIRR:FIRB:LB:PAD -> tile_hint, QD_NCO_ORDER, QD_CHUNK_MB, QD_COPY_THREADS."""
+    e = os.environ
+    kw = dict(kernel_policy=_ffi.KERNEL_AUTO)
+    if e.get("QD_NO_FIXED"):
+        kw["kernel_policy"] = _ffi.KERNEL_GENERIC
+    elif e.get("QD_JIT") == "1":
+        kw["kernel_policy"] = _ffi.KERNEL_SPECIALISE
+    elif e.get("QD_JIT") == "0":
+        kw["kernel_policy"] = _ffi.KERNEL_NO_PLAN_TIME
+    if e.get("QD_TUNE") and not e.get("QD_NO_FIXED"):
+        kw["tile_hint"] = [int(v) for v in e["QD_TUNE"].split(":")][:6]
+    if e.get("QD_NCO_ORDER") in ("1", "2"):
+        kw["nco_order"] = int(e["QD_NCO_ORDER"])
+    if e.get("QD_CHUNK_MB"):
+        kw["chunk_bytes"] = int(e["QD_CHUNK_MB"]) << 20
+    if e.get("QD_COPY_THREADS"):
+        kw["copy_threads"] = int(e["QD_COPY_THREADS"])
+    kw.update(overrides)
+    return kw
+
+
+class PinnedBuffer:
+    """Host memory from qd_host_alloc (QD_MEM_HOST_PINNED) viewed as a numpy uint8 array."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        check(lib().qd_host_alloc(max(int(nbytes), 1), C.byref(self.ptr)))
+        self.nbytes = int(nbytes)
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(max(self.nbytes, 1),))[:self.nbytes]
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib().qd_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Plan:
     """The fused chain  from -> [shift] -> [lowpass] -> sparkfft|bucket  (Operation::exec, src/lib.rs:83-175)."""
 
     def __init__(self, fmt, sample_rate, n_samples, shift_hz=None, lowpass=None, width=128, stride=None,
-                 epilogue=_ffi.EPI_NORMS_F32, rng=None):
+                 epilogue=_ffi.EPI_NORMS_F32, rng=None, options=None, **option_kw):
         d = _ffi.ChainDesc()
         d.struct_size = C.sizeof(_ffi.ChainDesc)
         d.format = fmt
@@ -128,7 +191,19 @@ class Plan:
             d.has_range, d.range_min, d.range_max = 1, rng[0], rng[1]
         self.desc = d
         self._h = C.c_void_p()
-        check(lib().qd_plan_create(C.byref(d), C.byref(self._h)))
+        if options is None:
+            kw = options_from_env(**option_kw)
+            options = plan_options(**kw)
+            hint_from_env = "tile_hint" in kw and "tile_hint" not in option_kw
+        else:
+            hint_from_env = False
+        rc = lib().qd_plan_create_ex(C.byref(d), C.byref(options), C.byref(self._h))
+        if rc == _ffi.ERR_INVALID and hint_from_env and b"tile_hint" in lib().qd_last_error():
+            kw.pop("tile_hint")                      # a sweep's tiling that does not fit this chain: the library's own choice
+            options = plan_options(**kw)
+            rc = lib().qd_plan_create_ex(C.byref(d), C.byref(options), C.byref(self._h))
+        check(rc)
+        self.options = options
         info = _ffi.PlanInfo()
         check(lib().qd_plan_get_info(self._h, C.byref(info)))
         self.info = info
@@ -167,17 +242,48 @@ class Plan:
             return (n_windows * self.width, 2), np.float32
         return (n_windows,), np.uint8
 
-    def run_host(self, data, first_window=0, n_windows=None, src_first=0):
-        """data: bytes / uint8 array holding source samples [src_first, ...).  Returns a numpy array."""
+    def run_host(self, data, first_window=0, n_windows=None, src_first=0, pinned=False, out=None):
+        """data: bytes / uint8 array holding source samples [src_first, ...).  Returns a numpy array.
+        pinned=True: `data` (and `out`, if given) are PinnedBuffer arrays -> QD_MEM_HOST_PINNED, no staging copy."""
         buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1))
         n_windows = self.n_windows - first_window if n_windows is None else n_windows
         shape, dt = self._out_shape_dtype(n_windows)
-        out = np.zeros(shape, dtype=dt)
+        out_mem = MEM_HOST
+        if out is None:
+            out = np.zeros(shape, dtype=dt)
+        else:
+            out = out.view(dt)[:int(np.prod(shape))].reshape(shape)
+            out_mem = _ffi.MEM_HOST_PINNED if pinned else MEM_HOST
         count = buf.size // _FMT_BYTES[self.desc.format]
         if n_windows:
-            check(lib().qd_plan_run(self._h, _np_ptr(buf), MEM_HOST, src_first, count, first_window, n_windows,
-                                    _np_ptr(out), MEM_HOST, None))
+            check(lib().qd_plan_run(self._h, _np_ptr(buf), _ffi.MEM_HOST_PINNED if pinned else MEM_HOST, src_first, count,
+                                    first_window, n_windows, _np_ptr(out), out_mem, None))
         return out
+
+    def stats(self):
+        st = _ffi.PlanStats()
+        check(lib().qd_plan_get_stats(self._h, C.byref(st)))
+        return st
+
+    def shard_info(self, g):
+        si = _ffi.ShardInfo()
+        check(lib().qd_plan_shard_info(self._h, g, C.byref(si)))
+        return si
+
+    def run_sharded_host(self, data, pinned=False):
+        """qd_plan_run_sharded: the whole stream from one host buffer over the plan's shards (one thread per shard)."""
+        buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1))
+        shape, dt = self._out_shape_dtype(self.n_windows)
+        out = np.zeros(shape, dtype=dt)
+        check(lib().qd_plan_run_sharded(self._h, _np_ptr(buf), _ffi.MEM_HOST_PINNED if pinned else MEM_HOST, _np_ptr(out), MEM_HOST))
+        return out
+
+    def run_sharded_device(self, slab_ptrs, out_ptrs, sync=True):
+        """qd_plan_run_sharded_device: slab_ptrs[g] / out_ptrs[g] are device addresses on shard g's device."""
+        n = len(slab_ptrs)
+        a = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in slab_ptrs])
+        b = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in out_ptrs])
+        check(lib().qd_plan_run_sharded_device(self._h, a, b, 1 if sync else 0))
 
     def run_device(self, src, out, first_window=0, n_windows=None, src_first=0, src_count=None, stream=None):
         """src/out: torch CUDA tensors (any dtype, contiguous).  Enqueues on torch's current stream."""

@@ -5,7 +5,7 @@
 wl=$1; shift
 for rep in 1 2 3; do
   for lib in "$@"; do
-    QD_LIB_PATH=$PWD/$lib python bench.py --workload $wl --no-cpu-baseline 2>/dev/null | \
-      python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$wl', '$lib', round(d['ms_per_step'],4), round(d['roofline']['frac'],3), flush=True)"
+    QD_LIB_PATH=$PWD/$lib python bench.py --workload $wl --no-cpu-baseline --no-others 2>/dev/null | \
+      python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$wl', '$lib', round(d['ms_per_step'],4), round(d["roofline"]["hbm"]["frac"],3), flush=True)"
   done
 done

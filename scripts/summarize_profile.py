@@ -3,7 +3,7 @@ import collections, csv, glob, json, os, sys
 
 out, tag = sys.argv[1], sys.argv[2]
 args = sys.argv[3:]
-workload = "cfg2"
+workload = "cfg3p"
 if "--workload" in args:
     workload = args[args.index("--workload") + 1]
 res = {"tag": tag, "workload": workload, "bench_args": args}

@@ -78,3 +78,38 @@ def test_product_never_imports_oracle():
                     if re.search(r"quadrs_oracle|from oracle|import oracle|qo_[a-z]", txt):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_options_struct_and_validation(engine):
+    """qd_plan_options is checked before any GPU call; sizes match the header's layout."""
+    from quadrs_amd import _ffi
+    assert C.sizeof(_ffi.PlanOptions) == 4 * 4 + 8 + 4 + 16 * 4 + 6 * 4 + 4 and C.sizeof(_ffi.ShardInfo) == 48 and C.sizeof(_ffi.PlanStats) == 40
+    kw = dict(fmt=engine.FMT_CF32, sample_rate=21_000_000, n_samples=1 << 20, width=128)
+    for bad in (dict(kernel_policy=9), dict(nco_order=3), dict(copy_threads=1000), dict(chunk_bytes=10)):
+        with pytest.raises(engine.QuadrsError) as ei:
+            engine.Plan(**kw, **bad)
+        assert ei.value.code == 1, bad
+    o = engine.plan_options()
+    o.struct_size = 12
+    with pytest.raises(engine.QuadrsError) as ei:
+        engine.Plan(**kw, options=o)
+    assert ei.value.code == 1
+
+
+def test_shipped_library_reads_no_tuning_environment(engine):
+    """'the C ABI takes an explicit struct, no env vars'.  The only getenv calls allowed in the product
+    source are the development-build helper (compiled to `return nullptr` without -DQD_DEVELOP) and the location of the
+    on-disk code-object cache; the ablation bits are compiled out of the kernels unless QD_DEVELOP is defined."""
+    src = open(os.path.join(ROOT, "quadrs_amd", "csrc", "quadrs_hip.hip")).read()
+    calls = [m.start() for m in re.finditer(r"\bgetenv\(", src)]
+    allowed = []
+    for pos in calls:
+        line = src[src.rfind("\n", 0, pos) + 1:src.find("\n", pos)]
+        allowed.append(("dev_env(const char *name)" in line) or any(k in line for k in ('"QD_JIT_CACHE"', '"XDG_CACHE_HOME"', '"HOME"')))
+    assert calls and all(allowed), [src[p - 40:p + 40] for p, ok in zip(calls, allowed) if not ok]
+    chain = open(os.path.join(ROOT, "quadrs_amd", "csrc", "qd_chain.h")).read()
+    assert "#ifdef QD_DEVELOP" in chain and not re.search(r"P\.dbg\s*&", chain)
+    import subprocess
+    strings = subprocess.run(["strings", "-a", engine._ffi.LIB_PATH], capture_output=True, text=True).stdout
+    for knob in ("QD_DEBUG_SKIP", "QD_TUNE", "QD_JIT_FLAGS", "QD_WG_PER_CU", "QD_NO_FIXED", "QD_CHUNK_MB"):
+        assert knob not in strings, knob

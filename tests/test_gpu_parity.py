@@ -8,9 +8,16 @@ Tolerances (written here once):
     an f32 rounding boundary (p ~ 1e-8) or the component itself is ~0 (zero crossings).  The cf32
     output is required to be within 1 ulp of the sample's magnitude (`complex_ulp_err <= 1`) and
     bit-exact for >= 99.9 % of samples.
-  * fused chain norms: bit-exact for >= 99.9 % of bins, never further than 4 ulp of the window's
-    largest norm (an NCO 1-ulp event propagates through 40-400 taps and a W-point FFT).
+  * fused chain norms: bit-exact for >= 99.99 % of bins, never further than 1 ulp of the window's
+    largest norm.  Why not 100 %: a chain with a shift stage inherits the NCO's rare 1-ulp multiplier events
+    (p ~ 1e-8 per sample), each of which touches the T/D decimated samples around it and, through the FFT,
+    every bin of that one window.  Chains without a shift stage are bit-exact.
+  * glyph codes / bucket digits: equal to the oracle's, except where the oracle's own value sits within
+    4 ulp of a decision threshold (edge-aware rule); such cells are counted and reported.
+Every chain comparison appends what it OBSERVED (bit-exact fraction, worst ulp) to
+gpurun_out/parity_observed.jsonl, so a drift inside the tolerance is visible.
 """
+import json
 import os
 
 import numpy as np
@@ -28,13 +35,46 @@ def vec():
     return np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
 
 
-def assert_norms_close(ref, got, what=""):
+_OBSERVED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_observed.jsonl")
+
+
+def record_observed(what, **kv):
+    """What a comparison measured (not just whether it passed): printed and appended to gpurun_out/parity_observed.jsonl."""
+    rec = dict(what=what, test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], **kv)
+    print("observed:", json.dumps(rec))
+    try:
+        os.makedirs(os.path.dirname(_OBSERVED), exist_ok=True)
+        with open(_OBSERVED, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+def assert_norms_close(ref, got, what="", min_exact=0.9999, max_ulp=1.0):
+    """Thresholds sit just above what the kernels are observed to do (see the module docstring): >= 99.99 % of bins
+    bit-exact, nothing further than 1 ulp of the window's largest norm; shift-free chains pass min_exact=1.0, max_ulp=0."""
     assert ref.shape == got.shape, (ref.shape, got.shape)
     exact = (ref.view(np.uint32) == got.view(np.uint32))
-    frac = exact.mean() if exact.size else 1.0
+    frac = float(exact.mean()) if exact.size else 1.0
     scale = ulp_of(ref.max(axis=-1, keepdims=True)).astype(np.float64)
-    worst = (np.abs(ref.astype(np.float64) - got.astype(np.float64)) / scale).max() if ref.size else 0.0
-    assert frac >= 0.999 and worst <= 4.0, f"{what}: bit-exact fraction {frac:.6f}, worst {worst:.2f} ulp(window max)"
+    worst = float((np.abs(ref.astype(np.float64) - got.astype(np.float64)) / scale).max()) if ref.size else 0.0
+    record_observed(what, bins=int(ref.size), exact_fraction=frac, worst_ulp_of_window_max=worst)
+    assert frac >= min_exact and worst <= max_ulp, f"{what}: bit-exact fraction {frac:.6f}, worst {worst:.2f} ulp(window max)"
+
+
+def assert_codes_edge_aware(ref_codes, got_codes, ref_norms, rmin, rmax, what, k_ulp=4):
+    """Glyph codes (src/fft.rs:54-60) must equal the oracle's; a cell may differ only where the oracle's own norm lies
+    within k ulp of one of the nine decision thresholds min + i*(max-min)/7."""
+    assert ref_codes.shape == got_codes.shape
+    diff = ref_codes != got_codes
+    step = (np.float32(rmax) - np.float32(rmin)) / np.float32(7.0)
+    edges = np.array([np.float32(rmin) + np.float32(i) * step for i in range(8)] + [np.float32(rmax)], dtype=np.float32)
+    nd = ref_norms[diff].astype(np.float64)
+    near = np.zeros(nd.shape, dtype=bool)
+    for e in edges:
+        near |= np.abs(nd - float(e)) <= k_ulp * float(np.spacing(np.float32(e)))
+    record_observed(what, cells=int(ref_codes.size), differing=int(diff.sum()), differing_near_threshold=int(near.sum()))
+    assert near.all(), f"{what}: {int((~near).sum())} glyph cells differ away from any threshold"
 
 
 # ------------------------------------------------------------------ A1 unpack
@@ -251,14 +291,21 @@ def test_glyph_and_bucket_epilogues(engine, oracle, fsk):
     p = engine.Plan(0, 21_000_000, n, shift_hz=280000, lowpass=(2_000_000, 16, 40), width=32, stride=8,
                     epilogue=engine.EPI_GLYPH_U8, rng=(0.01, 0.3))
     codes = p.run_host(data)
-    assert codes.shape == ref_codes.shape and (codes == ref_codes).mean() >= 0.9995
+    assert_codes_edge_aware(ref_codes, codes, ref_norms, 0.01, 0.3, "glyph fsk W=32 S=8")
     assert len(np.unique(ref_codes)) >= 5                      # the range really exercises the glyph ladder
     pb = engine.Plan(0, 21_000_000, n, shift_hz=280000, lowpass=(2_000_000, 16, 40), width=32, stride=8,
                      epilogue=engine.EPI_BUCKET2_U8)
     vals = pb.run_host(data)
     ref_vals = ch.freq_levels(32, 8)
     assert pb.n_windows == ref_vals.size == (ch.len() - 32) // 8   # floor count, not the strict-< loop
-    assert (vals == ref_vals).mean() >= 0.9995
+    # a bucket digit may differ only where the two half-spectrum sums (src/fft.rs:95-96) are within 4 ulp of each other
+    dv = np.flatnonzero(vals != ref_vals)
+    ref_norms_b = ref_norms[:vals.size].astype(np.float64)      # spark_fft's windows start at the same offsets (k*S)
+    halves = np.stack([ref_norms_b[:, :16].sum(axis=1), ref_norms_b[:, 16:].sum(axis=1)], axis=1)
+    record_observed("bucket fsk W=32 S=8", windows=int(vals.size), differing=int(dv.size))
+    for w in dv:
+        a, b = float(halves[w, 0]), float(halves[w, 1])
+        assert abs(a - b) <= 4 * float(np.spacing(np.float32(max(a, b)))), (int(w), a, b)
     # a stream whose tone hops between +f and -f exercises both digits (README's OOK/FSK use of `bucket`)
     t = np.arange(60_000)
     f = np.where((t // 5000) % 2 == 0, 0.11, -0.17)
@@ -401,8 +448,12 @@ def test_take_fft_rows(engine, oracle, fsk, W, out_len, windowing, slice_):
 
 
 def test_take_fft_errors(engine, fsk):
-    x = np.frombuffer(fsk, dtype=np.float32).reshape(-1, 2)[:5000]
-    for kw, code in ((dict(width=100, output_len=8), 5),                    # planner widths: not built
+    x_all = np.frombuffer(fsk, dtype=np.float32).reshape(-1, 2)
+    with pytest.raises(engine.QuadrsError) as ei:
+        engine.take_fft(x_all, width=10_000, output_len=8)                  # widths that are not a power of two: built up to 8192
+    assert ei.value.code == 5
+    x = x_all[:5000]
+    for kw, code in (
                      (dict(width=64, output_len=8, slice_=(10, 10)), 2),    # end > start assert
                      (dict(width=64, output_len=8, slice_=(10, 5000)), 2),  # end < len assert
                      (dict(width=64, output_len=6000), 1)):                 # ensure!(visible > output_len)
@@ -438,17 +489,16 @@ def test_cfg2_full_size_properties(engine, oracle):
     nw = p.n_windows
     seams = [int(b) + d for k in (2, 4, 8) for b in np.linspace(0, nw, k + 1)[1:-1] for d in range(-4, 5)]
     picks = sorted(set(list(range(1024)) + list(range(nw - 1024, nw)) + rng.integers(0, nw, 4096).tolist() + seams))
-    for w in picks:
+    refs = np.empty((len(picks), 128), dtype=np.float32)
+    for i, w in enumerate(picks):
         first, count = p.src_range(w, 1)
         slab = src[first:first + count].cpu().numpy()
-        ch = oracle.Chain.from_bytes(np.concatenate([slab, np.zeros((130, 2), np.float32)]).tobytes(), 0, 21_000_000)
         # absolute phase: apply the oracle's shift at the absolute offset, then lowpass + fft
         shifted = oracle.shift_apply(slab, first, oracle.shift_ratio(280000, 21_000_000))
         n_out, dec = oracle.lowpass_block(oracle.taps(2_000_000, 21_000_000, 40), 16, shifted)
         assert n_out == 128
-        ref = oracle.norm(oracle.fft(dec))[np.r_[64:128, 0:64]]
-        assert_norms_close(ref[None], host_out[w][None], f"cfg2 window {w}")
-        del ch
+        refs[i] = oracle.norm(oracle.fft(dec))[np.r_[64:128, 0:64]]
+    assert_norms_close(refs, host_out[picks], f"cfg2 full size, {len(picks)} sampled windows")
     # linearity: doubling the input doubles every norm exactly (power-of-two scaling is exact)
     src2 = src * 2
     out2 = torch.empty_like(out)
@@ -508,7 +558,8 @@ def test_full_size_chains(engine, oracle, name):
     picks = sorted(set(list(range(24)) + list(range(nw - 24, nw)) + rng.integers(0, nw, 96).tolist() + seams))
     taps = oracle.taps(lp[0], sr, T)
     ratio = oracle.shift_ratio(shift, sr) if shift is not None else None
-    for w in picks:
+    refs = np.empty((len(picks), W), dtype=np.float32)
+    for i, w in enumerate(picks):
         first, count = p.src_range(w, 1)
         raw = src[first:first + count].cpu().numpy()
         x = raw if fmt == 0 else oracle.unpack(fmt, raw.tobytes())
@@ -516,8 +567,12 @@ def test_full_size_chains(engine, oracle, name):
             x = oracle.shift_apply(x, first, ratio)
         n_out, dec = oracle.lowpass_block(taps, D, x)
         assert n_out == W
-        ref = oracle.norm(oracle.fft(dec))[np.r_[W // 2:W, 0:W // 2]]
-        assert_norms_close(ref[None], out[w].cpu().numpy()[None], f"{name} window {w}")
+        refs[i] = oracle.norm(oracle.fft(dec))[np.r_[W // 2:W, 0:W // 2]]
+    got = out[torch.as_tensor(picks, device="cuda")].cpu().numpy()
+    if ratio is None:
+        assert_norms_close(refs, got, f"{name} full size, {len(picks)} sampled windows", min_exact=1.0, max_ulp=0.0)
+    else:
+        assert_norms_close(refs, got, f"{name} full size, {len(picks)} sampled windows")
     # idempotence
     out2 = torch.empty_like(out)
     p.run_device(src, out2)

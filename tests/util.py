@@ -52,7 +52,7 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
     """Random chain shapes through the plan-time compiler (QD_JIT=1; a quarter of them with a QD_TUNE tiling that
     exercises the register-tiled FIR / 16-byte LDS rows / wide workgroups) against the generic kernel (QD_JIT=0),
     bit for bit; with `oracle` (tests only) the first windows are also checked against the CPU oracle: bit-exact without
-    a shift stage, within 4 ulp of the window maximum with one.  Returns (checked, mismatching descriptions).
+    a shift stage, within 1 ulp of the window maximum with one.  Returns (checked, mismatching descriptions).
     Q is the quadrs_amd package."""
     import os
     rng = np.random.default_rng(seed)
@@ -106,7 +106,7 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
                     both_nan = np.isnan(ref) & np.isnan(got)
                     with np.errstate(invalid="ignore"):
                         scale = ulp_of(np.nanmax(np.where(np.isnan(ref), -np.inf, ref), axis=-1, keepdims=True)).astype(np.float64)
-                        close = np.abs(ref.astype(np.float64) - got.astype(np.float64)) <= 4.0 * scale
+                        close = np.abs(ref.astype(np.float64) - got.astype(np.float64)) <= 1.0 * scale
                     ok = bool((close | both_nan).all())
             desc = f"fmt={fmt} W={W} S={S} D={D} T={T} shift={shift} N={N} epi={epi} tune={tune} kinds={info}"
             if log:
