@@ -54,7 +54,7 @@ LANES_PER_CHIP = 64 * 4 * 256          # 64 lanes x 4 SIMDs x 256 CUs
 def valu_ops_per_sample(cfg, nco_order):
     """Arithmetic of the exact-order chain per INPUT sample (SURVEY 8(d) formula, refined to instruction classes):
     f32 lane-operations and f64 lane-operations.  FIR: T/D taps per input sample, 2 components, separately rounded mul and
-    add; NCO (DESIGN.md section 4): 10 (first order) / 13 (second order) f64 ops + 2 f64->f32 converts, complex multiply 6 f32;
+    add; NCO (DESIGN.md section 4): 9 (first order) / 12 (second order) f64 ops + 2 f64->f32 converts, complex multiply 6 f32;
     FFT ~5 W log2 W flops per window; |X| per bin: 2 converts, f64 mul + fma, an IEEE f64 sqrt (= 18 f64 issue slots,
     measured 36 ns) and a convert; 8-bit unpack: ~2 integer ops per component, cs16: two IEEE f32 divides (~10 slots each)."""
     fc, D, T = cfg["lp"]
@@ -63,7 +63,7 @@ def valu_ops_per_sample(cfg, nco_order):
     f64 = 23.0 * W / (S * D)
     if cfg["shift"] is not None:
         f32 += 6.0
-        f64 += (13.0 if nco_order == 2 else 10.0) + 2.0
+        f64 += (12.0 if nco_order == 2 else 9.0) + 2.0
     f32 += {0: 0.0, 1: 4.0, 2: 6.0, 3: 24.0}[cfg["fmt"]]
     return f32, f64
 
@@ -286,7 +286,7 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
         samples_rank = nw * info.raw_step
         alg_bytes = me.need_count * bps + nw * cfg["W"] * 4        # per launch on this rank: read once + norms written
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        nco_order = 0 if cfg["shift"] is None else (2 if abs(info.ratio) * n_total > 134217728.0 else 1)
+        nco_order = 0 if cfg["shift"] is None else (2 if abs(info.ratio) * n_total > 268435456.0 else 1)
         valu_ms_roof, f32_ops, f64_ops = valu_roof_msamples(cfg, nco_order)
         kernel_msamples = samples_rank / (kernel_ms * 1e-3) / 1e6
         hbm_roof_msamples = HBM_PEAK_GBPS * 1e9 / (alg_bytes / samples_rank) / 1e6

@@ -103,7 +103,10 @@ int qd_fft_norm_batch(const qd_c32 *in, size_t W, size_t n_fft, size_t in_stride
  * window (windowing 1; src/ffts.rs:110-119, host f32 arithmetic like the reference); forward FFT;
  * fftshifted norms into rows[output_len*W].  `in` holds samples [in_first, in_first+n_in) of the
  * cf32 Samples being viewed, whose len() is samples_len.  has_slice 0 => (0, len - W) (:27-30).
- * Power-of-two W only: the reference's FftPlanner also takes other lengths (not built).
+ * Any W: a power of two goes through the chain kernel's Radix4 (bit-exact against the oracle's restatement); every other
+ * width up to 4096 (the front end's slider range, src/eui/mod.rs:157) through a Bluestein kernel carried in f64 — rustfft's
+ * result for those lengths depends on its planner and host SIMD path (parity unpinned), so the bins are the exact DFT of
+ * the windowed f32 samples rounded once to f32.
  * QD_ERR_PANIC / QD_ERR_INVALID mirror the asserts / ensure! at :32-48. */
 int qd_take_fft(const qd_c32 *in, uint64_t in_first, size_t n_in, uint64_t samples_len, int has_slice,
                 uint64_t start, uint64_t end, size_t W, int windowing, size_t output_len, float *rows, int mem);
@@ -166,9 +169,10 @@ typedef struct {
     uint64_t chunk_bytes;        /* source bytes per chunk of the host-resident path; 0: 64 MiB */
     uint32_t n_shards;           /* qd_plan_run_sharded*: number of window-range shards; 0 or 1: the current device only */
     int32_t  shard_device[QD_MAX_SHARDS];   /* HIP device of shard g (a device may serve several shards) */
-    uint32_t tile_hint[6];       /* tuning: force a plan-time build with this tiling — windows per tile, threads (256 /
+    uint32_t tile_hint[8];       /* tuning: force a plan-time build with this tiling — windows per tile, threads (256 /
                                     512 / 1024), FIR outputs per lane, FIR block taps, waves per SIMD the build is register-
-                                    budgeted for, LDS pad elements per row (1 / 2); all 0: the library's own choice */
+                                    budgeted for, LDS pad elements per row (1 / 2), tiles per FFT batch, workgroups per CU;
+                                    all 0: the library's own choice */
 } qd_plan_options;
 
 int qd_plan_create(const qd_chain_desc *desc, qd_plan **plan);

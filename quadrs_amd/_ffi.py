@@ -50,7 +50,7 @@ class PlanOptions(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("kernel_policy", C.c_int32), ("nco_order", C.c_int32),
         ("copy_threads", C.c_uint32), ("chunk_bytes", C.c_uint64), ("n_shards", C.c_uint32),
-        ("shard_device", C.c_int32 * MAX_SHARDS), ("tile_hint", C.c_uint32 * 6),
+        ("shard_device", C.c_int32 * MAX_SHARDS), ("tile_hint", C.c_uint32 * 8),
     ]
 
 

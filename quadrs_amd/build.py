@@ -19,7 +19,25 @@ OBJ_DIR = os.path.join(ROOT, "build", "obj")
 OUT = os.path.join(HERE, "libquadrs_hip.so")
 
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include")]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"),
+         "-Rpass-analysis=kernel-resource-usage"]
+# per-kernel register / scratch figures of the last build (hipcc's kernel-resource-usage remarks), audited by
+# tests/test_abi_cpu.py::test_builtin_kernels_do_not_spill: a scheduling accident that spills the FIR's products costs 8x
+RESOURCES = os.path.join(ROOT, "build", "kernel_resources.json")
+
+
+def parse_resource_remarks(text):
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    return out
 
 
 def hipcc():
@@ -62,11 +80,31 @@ def build(force=False, verbose=False, extra=()):
             cmd = [hipcc()] + FLAGS + more + list(extra) + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            procs.append((cmd, subprocess.Popen(cmd)))
+            procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
             objs.append(obj)
+        resources = {}
         for cmd, pr in procs:
-            if pr.wait() != 0:
+            _, err = pr.communicate()
+            resources.update(parse_resource_remarks(err))
+            kept, skip = [], 0            # a remark is three lines (message, source echo, caret) behind optional "In file included" lines
+            for l in err.splitlines():
+                if "[-Rpass-analysis=kernel-resource-usage]" in l:
+                    skip = 2
+                    while kept and kept[-1].startswith("In file included from"):
+                        kept.pop()
+                    continue
+                if skip:
+                    skip -= 1
+                    continue
+                kept.append(l)
+            diag = "\n".join(kept)
+            if diag.strip():
+                print(diag, file=sys.stderr)
+            if pr.returncode != 0:
                 raise subprocess.CalledProcessError(pr.returncode, cmd)
+        import json
+        with open(RESOURCES, "w") as f:
+            json.dump(resources, f, indent=0, sort_keys=True)
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lhiprtc", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

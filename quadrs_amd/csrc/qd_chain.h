@@ -45,6 +45,14 @@ namespace qd {
 
 constexpr int kThreads = 256;
 
+// Plan-time builds may bake the plan's filter into the code (FixedGeo FLAGS_ bit 1): the host puts
+// `#define QD_BAKED_TAPS_LIST 0x1.8p-7f, ...` (the designed taps, exact hex floats) in front of this header.
+#ifdef QD_BAKED_TAPS_LIST
+constexpr float kBakedTapTable[] = {QD_BAKED_TAPS_LIST};
+#else
+constexpr float kBakedTapTable[1] = {0.f};
+#endif
+
 // Timing-only ablation bits (ChainParams::dbg) exist in development builds (-DQD_DEVELOP: libquadrs_hip_dev.so, the
 // probe scripts) only; in the shipped library the tests compile to nothing.
 #ifdef QD_DEVELOP
@@ -121,9 +129,35 @@ constexpr uint32_t ct_raw_elems(uint32_t W, uint32_t S, uint32_t D, uint32_t T, 
     return (elems + 1) & ~1u;
 }
 
-template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1>
+// planar raw tile (FixedGeo FLAGS_ bit 0): floats per plane for a tile of tile_raw samples, rows of D floats at pitch DpP
+constexpr uint32_t ct_planar_pitch(uint32_t D) { return ((D / 4) % 2 == 1) ? D : D + 4; }     // 16-byte aligned, pitch/4 odd
+constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t T, uint32_t G) {
+    const uint32_t tile_raw = (G - 1) * S * D + W * D + T;
+    return ((tile_raw / D + 1) * ct_planar_pitch(D) + 7) & ~7u;
+}
+
+constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2;       // FixedGeo FLAGS_ bits
+
+template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1, uint32_t BATCH_ = 1,
+          uint32_t FLAGS_ = 0>
 struct FixedGeo {
     static constexpr bool kFixed = true;
+    static constexpr uint32_t kFlags = FLAGS_;
+    // Planar raw tile: the shifted samples are parked as two f32 planes (re / im) instead of interleaved pairs, rows of D floats
+    // at a 16-byte aligned pitch DpP with DpP/4 odd.  The component-split FIR then reads FOUR taps of its component with one
+    // conflict-free ds_read_b128 (256 B/clk) instead of two with a ds_read2_b32 (128 B/clk): half the LDS-array cycles and
+    // half the LDS instructions of the dominant loop.
+    static constexpr uint32_t DpP = ct_planar_pitch(D_);
+    static constexpr uint32_t plane_floats = ct_plane_floats(W_, S_, D_, T_, G_);
+    static constexpr bool planar_geometry = (FLAGS_ & kGeoPlanar) && ct_pow2(D_) && D_ % 8 == 0 && T_ % 4 == 0 && ((T_ - T_ / 2) % D_) % 4 == 0 && T_ >= 64 &&
+                                            ct_pow2(G_ * W_);
+    // Baked taps (plan-time builds only): the filter is a compile-time table, so every tap is an immediate operand of its
+    // multiply — no LDS reads, no registers, no lgkmcnt traffic for the taps at all.
+    static constexpr bool baked_request = (FLAGS_ & kGeoBakedTaps) != 0;
+    // FFT batching: the decimated windows of BATCH_ consecutive tiles of a workgroup are parked in LDS and transformed
+    // together.  The FFT + epilogue of ONE 128-point window keeps 16-32 of 256 lanes busy between three barriers and is
+    // pure latency; B windows at once cost the same latency for B times the work.
+    static constexpr uint32_t kBatch = BATCH_ ? BATCH_ : 1;
     static constexpr uint32_t kFirBlock = FIRB_;   // taps per software-pipelined FIR block (register budget knob)
     // outputs per lane in the FIR (register tiling): each LDS sample read feeds FIRR_ accumulators.
     // Needs 8-aligned geometry; falls back to 1 otherwise.
@@ -153,7 +187,7 @@ struct FixedGeo {
     static constexpr uint32_t log_base = logW <= 3 ? logW : ((logW & 1) ? 3u : 4u);
     static constexpr uint32_t base_len = 1u << log_base;
     static constexpr uint32_t layers = (logW - log_base) / 2;
-    static constexpr uint32_t lds_raw_elems = ct_raw_elems(W_, S_, D_, T_, G_, kPad ? kPad : 1);
+    static constexpr uint32_t lds_raw_elems_std = ct_raw_elems(W_, S_, D_, T_, G_, kPad ? kPad : 1);
     static constexpr uint32_t kNtrunc = c ? (c + D_ - 1) / D_ - 1 : 0;
     static constexpr bool kShared = T_ > 0 && S_ < W_ && kNtrunc <= S_;     // shared-FIR mode (see phase 2)
     // component-split FIR (fir_comp): mid-length filters whose tile leaves at least half the lanes without an output
@@ -168,10 +202,18 @@ struct FixedGeo {
     static constexpr bool split_ok_shared(uint32_t nt) {      // same, shared-FIR mode: (G-1)*S + W outputs per tile
         return kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * ((G_ - 1) * S_ + W_) <= nt;
     }
+    // the planar layout serves the component-split FIR of non-overlapping-window tiles (every 256-thread shape that asks for it)
+    static constexpr bool kPlanar = planar_geometry && split_ok(256u);
+    static constexpr bool kBakedTaps = baked_request && kPlanar;       // only the planar FIR takes its taps as immediates
+    static constexpr uint32_t lds_raw_elems = kPlanar ? plane_floats : lds_raw_elems_std;      // float2 elements
 };
 
 struct DynGeo {
     static constexpr bool kFixed = false;
+    static constexpr uint32_t kBatch = 1;
+    static constexpr uint32_t kFlags = 0;
+    static constexpr bool kPlanar = false, kBakedTaps = false;
+    static constexpr uint32_t DpP = 0, plane_floats = 0;
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
     static constexpr bool split_ok(uint32_t) { return false; }
@@ -300,7 +342,7 @@ __device__ __forceinline__ double prefetch_rowtab(const ChainParams &P, const Ti
 __device__ __forceinline__ RowBase load_rowbase(const ChainParams &P, uint64_t r) {
     const_f64_p rp = (const_f64_p)(uintptr_t)(P.rowtab + (r - P.rowtab_row0));
     RowBase rb;
-    rb.c = rp[0]; rb.s = rp[1]; rb.theta = rp[2]; rb.nf = rp[3];
+    rb.c = rp[0]; rb.s = rp[1]; rb.nf = rp[2]; rb.pad_ = 0.0;
     return rb;
 }
 
@@ -348,6 +390,27 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
 #pragma unroll
             for (int u = 0; u < SPL; ++u) x[u] = cmul(x[u], m[u]);   // buf[i] *= mul (src/shift.rs:51)
         }
+    }
+    if constexpr (GeoT::kPlanar && NT == 256) {
+        // planar tile: re plane, then im plane; sample m sits at float m + (DpP - D) * (m / D) of its plane.  rel is a
+        // multiple of D (tile starts and rows both are) and SPL divides D, so a lane's SPL samples are contiguous.
+        constexpr uint32_t LOGD = ct_log2(GeoT::D), PADP = GeoT::DpP - GeoT::D;
+        float *pre = reinterpret_cast<float *>(raw), *pim = pre + GeoT::plane_floats;
+        const int32_t off = m0 + (int32_t)PADP * (m0 >> LOGD);            // arithmetic shift: floor for the (never stored) negatives
+        if constexpr (INTERIOR) {
+            if constexpr (SPL == 2) {
+                *reinterpret_cast<float2 *>(pre + off) = make_float2(x[0].x, x[1].x);
+                *reinterpret_cast<float2 *>(pim + off) = make_float2(x[0].y, x[1].y);
+            } else {
+                *reinterpret_cast<float4 *>(pre + off) = make_float4(x[0].x, x[1].x, x[2].x, x[3].x);
+                *reinterpret_cast<float4 *>(pim + off) = make_float4(x[0].y, x[1].y, x[2].y, x[3].y);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < SPL; ++u)
+                if (m0 + u >= 0 && m0 + u < (int32_t)g.tile_raw) { pre[off + u] = x[u].x; pim[off + u] = x[u].y; }
+        }
+        return;
     }
     // Additive addressing: rel is a multiple of PD (n_start and ROW both are) and SPL divides PD, so
     // pad(rel + t) = pad_s(rel) + pad(t) and a lane's SPL samples are contiguous in LDS.
@@ -523,6 +586,7 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                         }
                     }
                 }
+                asm volatile("" : "+v"(accr), "+v"(acci));     // pin the add chain inside its block (see fir_comp)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (uint32_t i = 0; i < B; ++i) { xa[i] = xb[i]; ha[i] = hb[i]; }
@@ -724,12 +788,19 @@ __device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const 
     constexpr uint32_t NPAIR = NBLK / 2;                                   // blocks [0, 2*NPAIR) in ping-pong pairs
     load(0, xa, ha);
     // unroll explicitly: hipcc fully unrolls this loop for T = 200 on its own, hiprtc does not (10 % slower kernel)
+    // The accumulator is pinned at the end of every block (an empty asm that "modifies" it): sched_barrier only orders
+    // instructions with side effects, so without the pin instruction selection is free to sink the whole dependent add
+    // chain below the last sched_barrier of a fully unrolled body — every product is then computed early and SPILLED
+    // (185 VGPRs of scratch and 8.7x the run time on the 200-tap shape when a never-taken branch in front of this call
+    // was removed).
     auto pair = [&](uint32_t m) {
         load(m + 1, xb, hb);
         mac(m, xa, ha);
+        asm volatile("" : "+v"(acc));
         __builtin_amdgcn_sched_barrier(0);      // set A is reloaded only below its last use: no copies at the back edge
         load(m + 2, xa, ha);
         mac(m + 1, xb, hb);
+        asm volatile("" : "+v"(acc));
         __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (NPAIR <= 16) {
@@ -752,6 +823,48 @@ __device__ __forceinline__ float fir_comp(const float *xp, uint32_t jmax, const 
         acc = acc + xp[xoff(b + jj)] * h[jj];
     }
     if (snap_out) { *snap_out = snap; return acc; }      // shared-FIR mode keeps both (dec / trc)
+    return jmax < T ? snap : acc;
+}
+
+// Component-split FIR over the PLANAR tile (FixedGeo::kPlanar): a lane carries one accumulate chain — acc.re += x.re*h or
+// acc.im += x.im*h, the reference's two f32 chains (src/filter.rs:119), ascending taps, separately rounded multiply and add —
+// and reads FOUR consecutive taps' worth of its component with one ds_read_b128 (the plane's rows are 16-byte aligned at a
+// pitch whose quarter is odd: conflict-free in every 16-lane group).  xp = this lane's plane + the first float of the output's
+// first LDS row.  PF blocks are kept in flight.  With baked taps (plan-time builds) the taps are immediates; otherwise they are
+// broadcast ds_read_b128 from LDS.  A truncated output (jmax < T) is the accumulator snapshot at tap jmax, as in fir_span.
+template <class GeoT>
+__device__ __forceinline__ float fir_comp_planar(const float *xp, uint32_t jmax, const float *h) {
+    constexpr uint32_t D = GeoT::D, DpP = GeoT::DpP, T = GeoT::T, b = GeoT::b0, NB = T / 4;
+    constexpr int PF = GeoT::kFirBlock >= 4 ? (int)(GeoT::kFirBlock / 2) : 2;     // blocks of 4 taps in flight (FIRB 8 -> 4 blocks = 16 taps ahead)
+    static_assert(T % 4 == 0 && b % 4 == 0 && D % 4 == 0 && NB > (uint32_t)PF, "planar FIR geometry");
+    float acc = 0.f, snap = 0.f;
+    auto cand = [&](uint32_t jj) -> bool { return jj >= T / 2 + D && jj < T && ((jj - T / 2) % D) == 0; };
+    auto xoff = [&](uint32_t t) -> uint32_t { return (t / D) * DpP + (t % D); };
+    float4 x[PF], hh[PF];
+    auto load = [&](uint32_t k, int slot) {
+        x[slot] = *reinterpret_cast<const float4 *>(xp + xoff(b + 4 * k));
+        if constexpr (!GeoT::kBakedTaps) hh[slot] = *reinterpret_cast<const float4 *>(h + 4 * k);
+    };
+    auto tap = [&](uint32_t jj, int slot, int i) -> float {
+        if constexpr (GeoT::kBakedTaps) return kBakedTapTable[jj < sizeof(kBakedTapTable) / sizeof(float) ? jj : 0];
+        else return i == 0 ? hh[slot].x : (i == 1 ? hh[slot].y : (i == 2 ? hh[slot].z : hh[slot].w));
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load(k, k);
+#pragma unroll
+    for (uint32_t k = 0; k < NB; ++k) {
+        const int slot = (int)(k % PF);
+        const float xs[4] = {x[slot].x, x[slot].y, x[slot].z, x[slot].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t jj = 4 * k + i;
+            if (cand(jj)) { if (jmax == jj) snap = acc; }
+            acc = acc + xs[i] * tap(jj, slot, i);
+        }
+        asm volatile("" : "+v"(acc));                 // pin the add chain inside its block (see fir_comp)
+        if (k + PF < NB) load(k + PF, slot);           // refill the slot just consumed
+        __builtin_amdgcn_sched_barrier(0);
+    }
     return jmax < T ? snap : acc;
 }
 
@@ -815,13 +928,17 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
-    float2 *fb = raw + geo.lds_raw_elems;
-    float2 *twl = fb + (size_t)geo.G * geo.W;                 // radix-4 layer twiddles (< W entries), staged once
+    constexpr uint32_t kBatch = GeoT::kBatch;
+    constexpr uint32_t kLutElems = (FMT == 1 || FMT == 2) ? 256u : 0u;
+    float2 *fb0 = raw + geo.lds_raw_elems;                    // kBatch slots of G*W decimated samples (FFT buffers)
+    float2 *twl = fb0 + (size_t)kBatch * geo.G * geo.W;       // radix-4 layer twiddles (< W entries), staged once
     float *tapl = reinterpret_cast<float *>(twl + geo.W);     // FIR taps (T floats, padded to a multiple of 4)
-    float *lut = tapl + ((geo.T + 3) & ~3u);                  // 8-bit unpack table
+    float *lut = tapl + ((GeoT::kBakedTaps && NT == 256) ? 0u : ((geo.T + 3) & ~3u));   // 8-bit unpack table (8-bit formats only); baked taps take no LDS
     // shared-FIR mode (overlapping windows): every decimated output of the tile once + its truncated variant
-    float2 *dec = reinterpret_cast<float2 *>(lut + 256);
+    float2 *dec = reinterpret_cast<float2 *>(lut + kLutElems);
     float2 *trc = dec + ((geo.G - 1) * geo.S + geo.W);
+    // batched FFT: where each parked tile's output goes ({window index relative to out, low / high word; window count})
+    uint32_t *bmeta = reinterpret_cast<uint32_t *>(GeoT::kShared ? trc + ((geo.G - 1) * geo.S + geo.W) : dec);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
@@ -829,7 +946,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     if constexpr (FMT == 1) { if (tid < 256) lut[tid] = unpack_cs8(tid); }
     if constexpr (FMT == 2) { if (tid < 256) lut[tid] = unpack_cu8(tid); }
 
-    // Per-lane NCO constants: 4 doubles per sample slot.  Kernels whose FIR is register-hungry (register-tiled
+    // Per-lane NCO constants: 3 doubles per sample slot.  Kernels whose FIR is register-hungry (register-tiled
     // long filters) re-derive them at the top of every tile instead of keeping 8*SPL VGPRs live across the FIR
     // (the table is L2-resident; a tile of such a shape costs tens of thousands of cycles).
     constexpr bool kReloadLane = HAS_SHIFT && GeoT::kFixed && GeoT::kFirTile > 1;
@@ -840,7 +957,6 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             uint32_t j = first + u;
             double2 cs = P.jtab[j];
             lr[u].jf = (double)j;
-            lr[u].tj = lr[u].jf * P.ratio;
             lr[u].c = cs.x;
             lr[u].s = cs.y;
         }
@@ -855,7 +971,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         // ... and the taps: the FIR loop then contains LDS reads only, so its waits are counted
         // lgkmcnt(N) instead of a full drain per batch (scalar loads share that counter and return
         // out of order, which forces lgkmcnt(0)).
-        for (uint32_t i = tid; i < T; i += NT) tapl[i] = P.taps[i];
+        if constexpr (!(GeoT::kBakedTaps && NT == 256)) { for (uint32_t i = tid; i < T; i += NT) tapl[i] = P.taps[i]; }
     }
     __syncthreads();
 
@@ -885,6 +1001,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     }
 
     double rt_touch = 0.0;   // keeps the row-table L2 prefetch loads alive (see prefetch_rowtab)
+    uint32_t bslot = 0;      // parked tiles of the current FFT batch (wave-uniform)
     QD_STAMP_DECL
     QD_STAMP_START();
     while (tg.valid) {
@@ -968,6 +1085,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
         __builtin_amdgcn_s_setprio(1);
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
+        float2 *fb = fb0 + (size_t)bslot * geo.G * geo.W;     // this tile's slot of the FFT batch
         const uint32_t n_out = g_cnt << logW;
         const uint32_t log_width = 2 * geo.layers;   // width = W / base_len = 4^layers
         const bool cf32_out = !GeoT::kFixed && P.epi == 3;   // QD_EPI_CF32_BLOCKS (generic kernels only)
@@ -1052,13 +1170,24 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         }
         constexpr bool kSplit = HAS_FIR && GeoT::split_ok((uint32_t)NT);
         if constexpr (kSplit) {
-            for (uint32_t t = tid; t < 2u * n_out; t += NT) {
-                const uint32_t o = t >> 1, part = t & 1u;
+            constexpr bool kPlanarK = GeoT::kPlanar && NT == 256;
+            const uint32_t t_end = kPlanarK ? 2u * geo.G * geo.W : 2u * n_out;
+            for (uint32_t t = tid; t < t_end; t += NT) {
+                // interleaved tile: lanes alternate re / im of one output; planar tile: the first G*W lanes take the re chains,
+                // the next G*W the im chains, so a wave reads ONE plane at a lane stride of DpP floats (conflict-free b128)
+                uint32_t o = t >> 1, part = t & 1u;
+                if constexpr (GeoT::kPlanar && NT == 256) { o = t & (GeoT::G * GeoT::W - 1); part = t / (GeoT::G * GeoT::W); if (o >= n_out) continue; }
                 const uint32_t g = o >> logW, k = o & (W - 1);
                 uint32_t jmax = (W - k) * D + T / 2;
                 if (jmax > T) jmax = T;
-                const float *xp = reinterpret_cast<const float *>(raw + (size_t)(g * S + k + geo.a0) * Dp) + part;
-                const float v = QD_DBG(P, 2) ? xp[0] : fir_comp<GeoT>(xp, jmax, tapl);     // dbg: timing-only ablation
+                float v;
+                if constexpr (GeoT::kPlanar && NT == 256) {
+                    const float *xp = reinterpret_cast<const float *>(raw) + part * GeoT::plane_floats + (size_t)(g * S + k + geo.a0) * GeoT::DpP;
+                    v = QD_DBG(P, 2) ? xp[0] : fir_comp_planar<GeoT>(xp, jmax, tapl);
+                } else {
+                    const float *xp = reinterpret_cast<const float *>(raw + (size_t)(g * S + k + geo.a0) * Dp) + part;
+                    v = QD_DBG(P, 2) ? xp[0] : fir_comp<GeoT>(xp, jmax, tapl);     // dbg: timing-only ablation
+                }
                 const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
                 reinterpret_cast<float *>(fb + (g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base))[part] = v;
             }
@@ -1147,15 +1276,35 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             fb[(g << logW) + pos] = make_float2(accr, acci);
         }
         QD_STAMP_AT(2);
+        // Park this tile's window(s): remember where their output goes, advance to the next tile.  The FFT + epilogue run
+        // when the batch is full (or the workgroup has no further tile); the barrier below also keeps the next tile's
+        // phase 1 from overwriting raw samples another wave's FIR is still reading.
+        if constexpr (kBatch > 1) {
+            if (tid == 0) {
+                const uint64_t wr = w0 - P.out_window0;
+                bmeta[4 * bslot + 0] = (uint32_t)wr; bmeta[4 * bslot + 1] = (uint32_t)(wr >> 32); bmeta[4 * bslot + 2] = g_cnt;
+            }
+        }
+        ++bslot;
+        walk_local += walk_step;
+        tile = walk_tile(walk_local);
+        const TileGeo tg_next = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
+        const uint32_t batch_lim = (kBatch > 1 && P.epi != 2 && !cf32_out) ? kBatch : 1u;   // the bucket / write sinks flush every tile
+        const bool flush = bslot >= batch_lim || !tg_next.valid;                             // wave-uniform
         __syncthreads();
         QD_STAMP_AT(3);
+        if (!flush) { rt_touch += rt_pf; tg = tg_next; QD_STAMP_TILE(); continue; }
+        const uint32_t n_slots = bslot;
+        bslot = 0;
+        fb = fb0;
 
         __builtin_amdgcn_s_setprio(3);
-        // ---------------- phase 3: FFT (rustfft Radix4: base butterflies, then radix-4 layers)
+        // ---------------- phase 3: FFT (rustfft Radix4: base butterflies, then radix-4 layers) over the batch
+        const uint32_t fft_windows = kBatch > 1 ? n_slots * geo.G : g_cnt;      // parked slots hold G windows each (a short last tile leaves stale ones: transformed, never stored)
         if (!QD_DBG(P, 4) && !cf32_out) {
             const uint32_t base = geo.base_len;
             const uint32_t log_tpw = logW - geo.log_base;   // base tasks per window = W / base
-            const uint32_t n_task = g_cnt << log_tpw;
+            const uint32_t n_task = fft_windows << log_tpw;
             for (uint32_t t = tid; t < n_task; t += NT) {
                 // windows are contiguous in fb, so task t owns chunk t
                 float2 *d = fb + (size_t)t * base;
@@ -1187,7 +1336,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             const float2 *tw = twl;
             for (uint32_t layer = 0; layer < geo.layers; ++layer) {
                 __syncthreads();
-                const uint32_t n_bf = (g_cnt << logW) >> 2;   // W/4 butterflies per window
+                const uint32_t n_bf = (fft_windows << logW) >> 2;   // W/4 butterflies per window
                 for (uint32_t t = tid; t < n_bf; t += NT) {
                     // butterfly t: chunk (of 4*cols; windows are contiguous) t >> log_cols, column t & (cols-1)
                     const uint32_t chunk = t >> log_cols, i = t & (cols - 1);
@@ -1208,16 +1357,25 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         __syncthreads();
         QD_STAMP_AT(5);
 
-        // ---------------- phase 4: fftshift + norm + epilogue (out index is tile base + o: coalesced)
-        const uint64_t wrel = w0 - P.out_window0;
+        // ---------------- phase 4: fftshift + norm + epilogue (out index is tile base + o: coalesced), slot by slot
+        for (uint32_t sl = 0; sl < n_slots; ++sl) {
+        uint64_t wrel = w0 - P.out_window0;
+        uint32_t n_out_s = n_out;
+        const float2 *fbs = fb;
+        if constexpr (kBatch > 1) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(bmeta[4 * sl + 0]), hi = __builtin_amdgcn_readfirstlane(bmeta[4 * sl + 1]);
+            wrel = ((uint64_t)hi << 32) | lo;
+            n_out_s = __builtin_amdgcn_readfirstlane(bmeta[4 * sl + 2]) << logW;
+            fbs = fb + (size_t)sl * geo.G * geo.W;
+        }
         if (cf32_out) {
             // do_write / LowPass::read_at output (src/lib.rs:206-209): the decimated cf32 samples themselves
             float2 *outc = reinterpret_cast<float2 *>(P.out) + (wrel << logW);
-            for (uint32_t o = tid; o < n_out; o += NT) outc[o] = fb[o];
+            for (uint32_t o = tid; o < n_out_s; o += NT) outc[o] = fbs[o];
         } else if (P.epi == 2) {
             // freq_levels (src/fft.rs:95-97): sequential f32 sums of |X[k]| over each half
             float *nb = reinterpret_cast<float *>(raw);       // raw tile is dead now
-            for (uint32_t o = tid; o < n_out; o += NT) nb[o] = norm_ref(fb[o]);
+            for (uint32_t o = tid; o < n_out_s; o += NT) nb[o] = norm_ref(fbs[o]);
             __syncthreads();
             if (tid < g_cnt) {
                 const float *p = nb + (tid << logW);
@@ -1231,19 +1389,22 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         } else {
             float *outf = reinterpret_cast<float *>(P.out) + (wrel << logW);     // uniform base
             uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << logW);
-            for (uint32_t o = tid; o < n_out; o += NT) {
-                const float2 xv = fb[o ^ (W >> 1)];           // fftshift: bin (b + W/2) mod W of the same window
+            for (uint32_t o = tid; o < n_out_s; o += NT) {
+                // Lane offsets are kept opaque so hipcc does not hoist per-lane addresses (tid-derived, loop invariant) out of
+                // the tile loop into VGPRs that end up spilled: a scratch reload here waits with s_waitcnt vmcnt(0) — a full
+                // drain of the next tile's prefetch loads in every epilogue.
+                uint32_t oi = o;
+                asm volatile("" : "+v"(oi));
+                const float2 xv = fbs[oi ^ (W >> 1)];         // fftshift: bin (b + W/2) mod W of the same window
                 const float nm = QD_DBG(P, 8) ? xv.x : norm_ref(xv);
-                // The store address is uniform base + 32-bit lane offset.  Keep the offset opaque so hipcc does not
-                // hoist a per-lane 64-bit `P.out + tid*4` out of the tile loop: that pair was the kernel's one VGPR
-                // spill, and its scratch reload here carried an s_waitcnt vmcnt(0) — a full drain of the next tile's
-                // prefetch loads in every epilogue.
+                // the store address is uniform base + 32-bit lane offset, opaque for the same reason
                 uint32_t oo = o;
                 asm volatile("" : "+v"(oo));
                 if (QD_DBG(P, 16)) { asm volatile("" :: "v"(nm)); continue; }      // timing-only ablation: no output store
                 if (P.epi == 0) outf[oo] = nm;
                 else outb[oo] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
             }
+        }
         }
         rt_touch += rt_pf;       // first use of the touch loads: a whole tile after they were issued
         QD_STAMP_AT(6);
@@ -1253,9 +1414,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         if (P.epi == 2) __syncthreads();
         QD_STAMP_AT(7);
         QD_STAMP_TILE();
-        walk_local += walk_step;
-        tile = walk_tile(walk_local);
-        tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
+        tg = tg_next;
     }
     QD_STAMP_FLUSH();
     if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live

@@ -134,110 +134,85 @@ __device__ __forceinline__ uint32_t rev4(uint32_t x, uint32_t digits) {
 }
 
 // ---------------------------------------------------------------- NCO (src/shift.rs:49-50)
+//
+// Reference: place = fl((n as f64) * ratio); mul = (cos(place) as f32, sin(place) as f32).
+// A libm-grade f64 sincos per sample costs more f64 issue slots than the chip has at HBM rate, and f64 work also
+// lowers the clock the chip holds.  Scheme: the EXACT product X = n*ratio splits as n_r*ratio + j*ratio (n = n_r + j,
+// n_r the first sample of a row of ROW samples).  Tables hold cos/sin of those two exact products (each the libm
+// sincos of the rounded product, corrected to first order by the product's exactly known rounding residual), so one
+// rotation gives cos/sin(X).  The reference's argument is place = fl(X) = X - r with r = fma(n, ratio, -place) the exact
+// residual of ITS multiplication (|r| <= ulp(place)/2), so cos(place) = cos(X - r) = C + r*S, sin(place) = S - r*C to
+// first order (the dropped r^2/2 is <= 1.1e-16 for |place| < 2^28 rad; beyond that the second-order form is used).
+// 9 f64 operations per sample (12 second-order) + two f64->f32 converts; absolute error ~4e-16, so the f32 rounding
+// equals glibc's except when the f64 value lies within ~1e-8 f32-ulp of a rounding boundary.
 
 // Row-base entry: everything that is uniform over one row of ROW consecutive samples.
 struct __attribute__((aligned(32))) RowBase {
-    double c, s;     // cos/sin of theta
-    double theta;    // fl((double)(row*ROW) * ratio)  — the reference's `place` at the row start
+    double c, s;     // cos/sin of the exact product (row*ROW) * ratio
     double nf;       // (double)(row*ROW)
+    double pad_;
 };
 
-// Per-lane constants for one sample slot j inside a row: tj = fl(j*ratio), cos/sin(tj).
-struct LaneRot { double jf, tj, c, s; };
+// Per-lane constants for one sample slot j inside a row: cos/sin of the exact product j * ratio.
+struct LaneRot { double jf, c, s; };
 
-// Multiplier (cos(place) as f32, sin(place) as f32) with place = fl((double)n * ratio),
-// n = row start + j.  place is formed exactly as the reference forms it; its cosine/sine are
-// obtained by rotating the row base by d = place - theta_row (an exact f64 difference),
-// d = tj + e with |e| <= ~ulp(place): cos/sin(d) from the lane constants plus a first or
-// second order correction in e.  Total error ~4e-16, so the f32 rounding equals glibc's
-// except when the f64 value lies within ~1e-8 f32-ulp of a rounding boundary.
+// table entry: cos/sin of the exact product k * ratio, from the platform sincos of the rounded product
+__device__ __forceinline__ void nco_table_entry(double kf, double ratio, double *c, double *s) {
+    const double th = kf * ratio;
+    const double lo = __builtin_fma(kf, ratio, -th);     // exact: k*ratio = th + lo
+    double s0, c0;
+    sincos(th, &s0, &c0);
+    // cos / sin(th + lo), |lo| <= ulp(th)/2 (up to ~4e-6 at the far end of a 2^34-sample stream): third order in lo, the
+    // small terms gathered first so that each entry takes one final rounding
+    const double q = 0.5 * lo * lo, sl = __builtin_fma(-lo * lo * lo, 1.0 / 6.0, lo);     // 1 - cos lo, sin lo
+    *c = c0 + __builtin_fma(-q, c0, -sl * s0);
+    *s = s0 + __builtin_fma(-q, s0, sl * c0);
+}
+
 template <bool SECOND_ORDER>
 __device__ __forceinline__ float2 nco_mul(const RowBase &rb, const LaneRot &lr, double ratio) {
-    double nf = rb.nf + lr.jf;          // exact (integers < 2^53)
-    double place = nf * ratio;          // == reference `place`
-    double d = place - rb.theta;        // exact (Sterbenz)
-    double e = d - lr.tj;               // exact
-    double cd, sd;
+    const double nf = rb.nf + lr.jf;                     // exact (integers < 2^53)
+    const double place = nf * ratio;                     // == reference `place`
+    const double r = __builtin_fma(nf, ratio, -place);   // exact: n*ratio = place + r
+    const double C = __builtin_fma(-rb.s, lr.s, rb.c * lr.c);      // cos / sin of the exact product
+    const double S = __builtin_fma(rb.s, lr.c, rb.c * lr.s);
+    double c, s;
     if constexpr (SECOND_ORDER) {
-        double h = 0.5 * e;
-        double u = __builtin_fma(h, lr.c, lr.s);
-        double v = __builtin_fma(-h, lr.s, lr.c);
-        cd = __builtin_fma(-e, u, lr.c);
-        sd = __builtin_fma(e, v, lr.s);
+        const double h = 0.5 * r;
+        c = __builtin_fma(r, __builtin_fma(-h, C, S), C);          // C (1 - r^2/2) + r S
+        s = __builtin_fma(-r, __builtin_fma(h, S, C), S);          // S (1 - r^2/2) - r C
     } else {
-        cd = __builtin_fma(-e, lr.s, lr.c);
-        sd = __builtin_fma(e, lr.c, lr.s);
+        c = __builtin_fma(r, S, C);
+        s = __builtin_fma(-r, C, S);
     }
-    double c = __builtin_fma(-rb.s, sd, rb.c * cd);
-    double s = __builtin_fma(rb.c, sd, rb.s * cd);
     return make_float2((float)c, (float)s);
 }
 
 // The same arithmetic for the N samples a lane owns, written step-by-step across the samples so
-// that the N independent f64 dependency chains are issued interleaved (the chain is ~10 ops deep;
-// issued one sample after the other the wave stalls on every result).
+// that the N independent f64 dependency chains are issued interleaved.
 template <bool SECOND_ORDER, int N>
 __device__ __forceinline__ void nco_mul_n(const RowBase &rb, const LaneRot *lr, double ratio, float2 *m) {
-    double e[N], cd[N], sd[N], c[N], s[N];
+    double nf[N], pl[N], r[N], C[N], S[N], c[N], s[N];
 #pragma unroll
-    for (int u = 0; u < N; ++u) e[u] = rb.nf + lr[u].jf;
+    for (int u = 0; u < N; ++u) nf[u] = rb.nf + lr[u].jf;
 #pragma unroll
-    for (int u = 0; u < N; ++u) e[u] = e[u] * ratio;
+    for (int u = 0; u < N; ++u) { pl[u] = nf[u] * ratio; C[u] = rb.c * lr[u].c; S[u] = rb.c * lr[u].s; }
 #pragma unroll
-    for (int u = 0; u < N; ++u) e[u] = e[u] - rb.theta;
-#pragma unroll
-    for (int u = 0; u < N; ++u) e[u] = e[u] - lr[u].tj;
+    for (int u = 0; u < N; ++u) { r[u] = __builtin_fma(nf[u], ratio, -pl[u]); C[u] = __builtin_fma(-rb.s, lr[u].s, C[u]); S[u] = __builtin_fma(rb.s, lr[u].c, S[u]); }
     if constexpr (SECOND_ORDER) {
         double h[N], uu[N], vv[N];
 #pragma unroll
-        for (int u = 0; u < N; ++u) h[u] = 0.5 * e[u];
+        for (int u = 0; u < N; ++u) h[u] = 0.5 * r[u];
 #pragma unroll
-        for (int u = 0; u < N; ++u) { uu[u] = __builtin_fma(h[u], lr[u].c, lr[u].s); vv[u] = __builtin_fma(-h[u], lr[u].s, lr[u].c); }
+        for (int u = 0; u < N; ++u) { uu[u] = __builtin_fma(-h[u], C[u], S[u]); vv[u] = __builtin_fma(h[u], S[u], C[u]); }
 #pragma unroll
-        for (int u = 0; u < N; ++u) { cd[u] = __builtin_fma(-e[u], uu[u], lr[u].c); sd[u] = __builtin_fma(e[u], vv[u], lr[u].s); }
+        for (int u = 0; u < N; ++u) { c[u] = __builtin_fma(r[u], uu[u], C[u]); s[u] = __builtin_fma(-r[u], vv[u], S[u]); }
     } else {
 #pragma unroll
-        for (int u = 0; u < N; ++u) { cd[u] = __builtin_fma(-e[u], lr[u].s, lr[u].c); sd[u] = __builtin_fma(e[u], lr[u].c, lr[u].s); }
+        for (int u = 0; u < N; ++u) { c[u] = __builtin_fma(r[u], S[u], C[u]); s[u] = __builtin_fma(-r[u], C[u], S[u]); }
     }
-#pragma unroll
-    for (int u = 0; u < N; ++u) { c[u] = rb.c * cd[u]; s[u] = rb.s * cd[u]; }
-#pragma unroll
-    for (int u = 0; u < N; ++u) { c[u] = __builtin_fma(-rb.s, sd[u], c[u]); s[u] = __builtin_fma(rb.c, sd[u], s[u]); }
 #pragma unroll
     for (int u = 0; u < N; ++u) m[u] = make_float2((float)c[u], (float)s[u]);
-}
-
-// NCO multipliers for M samples that may sit in different rows: per-sample row constants.
-// Same arithmetic as nco_mul, interleaved across the M independent chains.
-template <bool SECOND_ORDER, int M>
-__device__ __forceinline__ void nco_mul_m(const RowBase *const *rb, const LaneRot *const *lr, double ratio, float2 *m) {
-    double e[M], cd[M], sd[M], c[M], s[M];
-#pragma unroll
-    for (int u = 0; u < M; ++u) e[u] = rb[u]->nf + lr[u]->jf;
-#pragma unroll
-    for (int u = 0; u < M; ++u) e[u] = e[u] * ratio;
-#pragma unroll
-    for (int u = 0; u < M; ++u) e[u] = e[u] - rb[u]->theta;
-#pragma unroll
-    for (int u = 0; u < M; ++u) e[u] = e[u] - lr[u]->tj;
-    if constexpr (SECOND_ORDER) {
-        double h[M], uu[M], vv[M];
-#pragma unroll
-        for (int u = 0; u < M; ++u) h[u] = 0.5 * e[u];
-#pragma unroll
-        for (int u = 0; u < M; ++u) { uu[u] = __builtin_fma(h[u], lr[u]->c, lr[u]->s); vv[u] = __builtin_fma(-h[u], lr[u]->s, lr[u]->c); }
-#pragma unroll
-        for (int u = 0; u < M; ++u) { cd[u] = __builtin_fma(-e[u], uu[u], lr[u]->c); sd[u] = __builtin_fma(e[u], vv[u], lr[u]->s); }
-    } else {
-#pragma unroll
-        for (int u = 0; u < M; ++u) { cd[u] = __builtin_fma(-e[u], lr[u]->s, lr[u]->c); sd[u] = __builtin_fma(e[u], lr[u]->c, lr[u]->s); }
-    }
-#pragma unroll
-    for (int u = 0; u < M; ++u) { c[u] = rb[u]->c * cd[u]; s[u] = rb[u]->s * cd[u]; }
-#pragma unroll
-    for (int u = 0; u < M; ++u) { c[u] = __builtin_fma(-rb[u]->s, sd[u], c[u]); s[u] = __builtin_fma(rb[u]->c, sd[u], s[u]); }
-#pragma unroll
-    for (int u = 0; u < M; ++u) m[u] = make_float2((float)c[u], (float)s[u]);
 }
 
 }  // namespace qd

@@ -69,25 +69,23 @@ int bps_of(int fmt) { return fmt == QD_FMT_CF32 ? 8 : (fmt == QD_FMT_CS16 ? 4 : 
 
 // ------------------------------------------------------------------ small kernels
 
-// Row bases: (cos, sin)(fl((double)(row*ROW) * ratio)), plus theta and nf themselves.
+// Row bases: (cos, sin) of the exact product (row*ROW) * ratio (qd_device.h, NCO), plus nf itself.
 __global__ void k_rowtab(double ratio, uint32_t row_len, uint64_t row0, uint64_t n_rows, RowBase *out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
-    double nf = (double)((row0 + i) * (uint64_t)row_len);
-    double th = nf * ratio;
-    double s, c;
-    sincos(th, &s, &c);
     RowBase rb;
-    rb.c = c; rb.s = s; rb.theta = th; rb.nf = nf;
+    rb.nf = (double)((row0 + i) * (uint64_t)row_len);
+    rb.pad_ = 0.0;
+    nco_table_entry(rb.nf, ratio, &rb.c, &rb.s);
     out[i] = rb;
 }
 
+// Lane table: (cos, sin) of the exact product j * ratio
 __global__ void k_jtab(double ratio, uint32_t n, double2 *out) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    double tj = (double)j * ratio;
     double s, c;
-    sincos(tj, &s, &c);
+    nco_table_entry((double)j, ratio, &c, &s);
     out[j] = make_double2(c, s);
 }
 
@@ -115,7 +113,7 @@ __global__ __launch_bounds__(256) void k_shift(float2 *buf, uint64_t abs_off, ui
     for (int u = 0; u < 2; ++u) {
         uint32_t j = tid * 2 + u;
         double2 cs = jtab[j];
-        lr[u].jf = (double)j; lr[u].tj = lr[u].jf * ratio; lr[u].c = cs.x; lr[u].s = cs.y;
+        lr[u].jf = (double)j; lr[u].c = cs.x; lr[u].s = cs.y;
     }
     for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
         const RowBase rb = rowtab[r];
@@ -169,23 +167,29 @@ __global__ void k_gen(const int64_t *cos_hz, uint32_t n_cos, uint64_t sample_rat
 // c[n] = e^{-i pi n^2 / W}, b = conj(c) — a circular convolution of length M >= 2W-1 (a power of two), done in LDS as
 // forward radix-2 DIF (natural in, bit-reversed out) -> pointwise product with the precomputed spectrum of b (stored
 // bit-reversed, 1/M folded in) -> inverse radix-2 DIT (bit-reversed in, natural out): no permutation pass.
-// One workgroup per output row.  rustfft's own result for such lengths depends on the host's SIMD code path, so there is
-// no bit pattern to match (parity unpinned); tests bound it against an f64 DFT (tests/test_gpu_parity.py).
+// One workgroup per output row.  rustfft's own result for such lengths depends on the planner's decomposition and the
+// host's SIMD code path, so there is no bit pattern to match (PARITY UNPINNED).  The convolution is therefore carried in
+// f64 (the f32 window product of src/ffts.rs:64-68 first, exactly as the reference forms it): the bins come out as the
+// mathematically exact DFT of the windowed f32 samples rounded once to f32 — an f32 Bluestein would sit 5-10x further from
+// the exact answer than rustfft's mixed-radix paths do on smooth lengths.  Cost: ~1 ms for 2048 rows at M = 8192.
+__device__ __forceinline__ double2 zmul(double2 a, double2 b) {
+    return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
+}
 __global__ __launch_bounds__(256) void k_bluestein(const float2 *__restrict__ in, uint64_t in_first, const uint64_t *__restrict__ offs,
                                                    const float *__restrict__ win, uint32_t W, uint32_t M, uint32_t logM,
-                                                   const float2 *__restrict__ chirp, const float2 *__restrict__ Bbr,
-                                                   const float2 *__restrict__ tw, float *__restrict__ out) {
+                                                   const double2 *__restrict__ chirp, const double2 *__restrict__ Bbr,
+                                                   const double2 *__restrict__ tw, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    float2 *buf = reinterpret_cast<float2 *>(smem_b);
+    double2 *buf = reinterpret_cast<double2 *>(smem_b);
     const uint32_t tid = threadIdx.x;
     const uint64_t row = blockIdx.x;
     const float2 *x = in + (offs[row] - in_first);
     for (uint32_t n = tid; n < M; n += 256) {
-        float2 v = make_float2(0.f, 0.f);
+        double2 v = make_double2(0.0, 0.0);
         if (n < W) {
-            v = x[n];
-            if (win) v = cscale(v, win[n]);           // *sample *= w_val (src/ffts.rs:64-68), Complex<f32> * f32
-            v = cmul(v, chirp[n]);
+            float2 xv = x[n];
+            if (win) xv = cscale(xv, win[n]);         // *sample *= w_val (src/ffts.rs:64-68), Complex<f32> * f32, f32-rounded
+            v = zmul(make_double2((double)xv.x, (double)xv.y), chirp[n]);
         }
         buf[n] = v;
     }
@@ -194,29 +198,30 @@ __global__ __launch_bounds__(256) void k_bluestein(const float2 *__restrict__ in
         const uint32_t h = 1u << sh;
         for (uint32_t t = tid; t < M / 2; t += 256) {
             const uint32_t j = t & (h - 1), i = ((t >> sh) << (sh + 1)) | j;
-            const float2 u = buf[i], v = buf[i + h];
-            buf[i] = cadd(u, v);
-            buf[i + h] = cmul(csub(u, v), tw[j << (logM - 1 - sh)]);
+            const double2 u = buf[i], v = buf[i + h];
+            buf[i] = make_double2(u.x + v.x, u.y + v.y);
+            buf[i + h] = zmul(make_double2(u.x - v.x, u.y - v.y), tw[j << (logM - 1 - sh)]);
         }
         __syncthreads();
     }
-    for (uint32_t r = tid; r < M; r += 256) buf[r] = cmul(buf[r], Bbr[r]);
+    for (uint32_t r = tid; r < M; r += 256) buf[r] = zmul(buf[r], Bbr[r]);
     __syncthreads();
     for (uint32_t sh = 0; sh < logM; ++sh) {          // DIT with conjugate twiddles
         const uint32_t h = 1u << sh;
         for (uint32_t t = tid; t < M / 2; t += 256) {
             const uint32_t j = t & (h - 1), i = ((t >> sh) << (sh + 1)) | j;
-            const float2 u = buf[i], v = cmul(buf[i + h], cconj(tw[j << (logM - 1 - sh)]));
-            buf[i] = cadd(u, v);
-            buf[i + h] = csub(u, v);
+            const double2 w = tw[j << (logM - 1 - sh)];
+            const double2 u = buf[i], v = zmul(buf[i + h], make_double2(w.x, -w.y));
+            buf[i] = make_double2(u.x + v.x, u.y + v.y);
+            buf[i + h] = make_double2(u.x - v.x, u.y - v.y);
         }
         __syncthreads();
     }
     const uint32_t half = W / 2;                       // skip(W/2).chain(take(W/2)), src/ffts.rs:72-78
     for (uint32_t k = tid; k < W; k += 256) {
-        const float2 y = cmul(buf[k], chirp[k]);
+        const double2 y = zmul(buf[k], chirp[k]);
         const uint32_t pos = k >= half ? k - half : k + (W - half);
-        out[row * W + pos] = norm_ref(y);
+        out[row * W + pos] = norm_ref(make_float2((float)y.x, (float)y.y));     // the FFT result is Complex<f32>; norm() = hypotf
     }
 }
 
@@ -328,10 +333,11 @@ const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t 
 // process.  QD_JIT=0 disables, QD_JIT=1 forces it for every plan; by default only streams whose chain
 // input is >= 16 MiB pay the ~0.3 s compile.
 struct JitKey {
-    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1; int noslp = 0; uint32_t pad = 1;
+    int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1; int noslp = 0; uint32_t pad = 1, batch = 1, flags = 0;
+    uint64_t taps_hash = 0;        // baked-taps builds: FNV-1a of the filter (the code depends on it)
     bool operator<(const JitKey &o) const {
-        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr, noslp, pad) <
-               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr, o.noslp, o.pad);
+        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr, noslp, pad, batch, flags, taps_hash) <
+               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr, o.noslp, o.pad, o.batch, o.flags, o.taps_hash);
     }
 };
 std::mutex g_jit_mu;
@@ -378,7 +384,7 @@ std::string jit_cache_dir() {
 
 // returns nullptr (and leaves a message in *why) when specialisation is not possible; with may_compile false only the
 // in-process and on-disk caches are consulted
-hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compile = true) {
+hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compile = true, const std::vector<float> *taps = nullptr) {
     std::lock_guard<std::mutex> lock(g_jit_mu);
     auto it = g_jit_cache.find(k);
     if (it != g_jit_cache.end()) return it->second;
@@ -389,9 +395,16 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         return nullptr;
     }
     char name[512];
-    snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
-             k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
-    std::string src = std::string("#include \"qd_chain.h\"\ntemplate __global__ void ") + name + "(const qd::ChainParams);\n";
+    snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
+             k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
+    std::string src;
+    if ((k.flags & kGeoBakedTaps) && taps && !taps->empty()) {       // the plan's filter as exact hex-float literals
+        src += "#define QD_BAKED_TAPS_LIST ";
+        char lit[48];
+        for (size_t i = 0; i < taps->size(); ++i) { snprintf(lit, sizeof lit, "%s%af", i ? ", " : "", (double)(*taps)[i]); src += lit; }
+        src += "\n";
+    }
+    src += std::string("#include \"qd_chain.h\"\ntemplate __global__ void ") + name + "(const qd::ChainParams);\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "qd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *why = "hiprtcCreateProgram failed"; return nullptr; }
     hiprtcAddNameExpression(prog, name);
@@ -418,6 +431,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     std::string cache_file;
     {
         uint64_t h = fnv1a(name, strlen(name));
+        h = fnv1a(src.data(), src.size(), h);                  // includes the baked filter, if any
         int rtc_major = 0, rtc_minor = 0;                      // a code object does not outlive the compiler that made it
         (void)hiprtcVersion(&rtc_major, &rtc_minor);
         h = fnv1a(&rtc_major, sizeof rtc_major, h);
@@ -486,16 +500,32 @@ struct Geometry {
     size_t lds_bytes = 0;
 };
 
-size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems, uint32_t pad_per_row = 1) {
-    uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
-    uint64_t pad = (D % 2 == 0) ? pad_per_row * (tile_raw / D + 1) : 0;
-    uint64_t elems = tile_raw + pad + 1;
-    uint64_t min_elems = (uint64_t)G * W / 2 + 1;     // bucket epilogue parks G*W f32 norms here
-    if (elems < min_elems) elems = min_elems;
-    elems = (elems + 1) & ~1ull;                      // keep fb 16-byte aligned
-    if (raw_elems) *raw_elems = (uint32_t)elems;
-    uint64_t shared_fir = (T && S < W) ? 2 * ((uint64_t)(G - 1) * S + W) * 8 : 0;   // dec[] + trc[] of the shared-FIR mode
-    return (size_t)(elems * 8 + (uint64_t)G * W * 8 + W * 8 + ((T + 3) & ~3ull) * 4 + 256 * 4 + shared_fir);   // raw tile + FFT buffer + twiddles + taps + 8-bit LUT (+ shared FIR)
+// Dynamic LDS of a chain kernel with this tiling.  Layout (qd_chain.h, k_chain prologue): raw tile | batch x G*W FFT buffers |
+// twiddles | taps | 8-bit LUT | shared-FIR dec/trc | batch bookkeeping.  The generic kernels (interleaved tile, pad 1, batch 1,
+// taps in LDS) run inside the same allocation for the unaligned slab tail, so the size is the larger of the two layouts.
+size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems, uint32_t pad_per_row = 1, uint32_t batch = 1,
+               bool lut8 = true, uint32_t flags = 0) {
+    const uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
+    auto interleaved = [&](uint32_t padv) {
+        const uint64_t pad = (D % 2 == 0) ? padv * (tile_raw / D + 1) : 0;
+        uint64_t elems = tile_raw + pad + 1;
+        const uint64_t min_elems = (uint64_t)G * W / 2 + 1;     // bucket epilogue parks G*W f32 norms here
+        if (elems < min_elems) elems = min_elems;
+        return (elems + 1) & ~1ull;                             // keep fb 16-byte aligned
+    };
+    const uint64_t shared_fir = (T && S < W) ? 2 * ((uint64_t)(G - 1) * S + W) * 8 : 0;   // dec[] + trc[] of the shared-FIR mode
+    const uint64_t taps_b = ((T + 3) & ~3ull) * 4, lut_b = lut8 ? 256 * 4 : 0;
+    uint64_t elems = interleaved(pad_per_row);
+    // planar tile + immediates for taps (FixedGeo::kPlanar / kBakedTaps; the kernel falls back to the interleaved layout
+    // when its geometry conditions fail, which only needs less)
+    const bool planar = (flags & kGeoPlanar) && tile_raw < (1u << 24);
+    if (planar) { const uint64_t pe = ct_plane_floats((uint32_t)W, (uint32_t)S, (uint32_t)D, (uint32_t)T, G); if (pe > elems) elems = pe; }
+    // *raw_elems is what the runtime-geometry kernels read (ChainParams::lds_raw_elems): THEIR raw tile, whatever the main kernel's
+    if (raw_elems) *raw_elems = (uint32_t)interleaved(1);
+    const bool baked = planar && (flags & kGeoBakedTaps);
+    const uint64_t main_b = elems * 8 + (uint64_t)batch * G * W * 8 + W * 8 + (baked ? 0 : taps_b) + lut_b + shared_fir + (uint64_t)batch * 16;
+    const uint64_t generic_b = interleaved(1) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16;
+    return (size_t)(main_b > generic_b ? main_b : generic_b);
 }
 
 constexpr size_t kLdsMax = 160 * 1024;
@@ -786,9 +816,9 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->ratio = p->has_shift ? qd_shift_ratio(d.shift_hz, d.sample_rate) : 0.0;
 
     // |place| = n*|ratio| over the whole stream decides the NCO order once per plan: the dropped
-    // second-order term is e^2/2 with |e| <= 1.5 ulp(place); below 2^27 rad that is <= 2.5e-16, inside the
+    // second-order term is r^2/2 with |r| <= ulp(place)/2; below 2^28 rad that is <= 1.1e-16, inside the
     // scheme's ~4e-16 error budget, above it the second-order kernel is used
-    p->nco = !p->has_shift ? 0 : ((std::fabs(p->ratio) * (double)d.n_samples > 134217728.0) ? 2 : 1);
+    p->nco = !p->has_shift ? 0 : ((std::fabs(p->ratio) * (double)d.n_samples > 268435456.0) ? 2 : 1);
     if (p->has_shift && (p->opt.nco_order == 1 || p->opt.nco_order == 2)) p->nco = p->opt.nco_order;
     if (const char *e = dev_env("QD_DEBUG_SKIP")) p->dbg = (uint32_t)atoi(e);     // development builds: timing-only ablation
     const int policy = p->opt.kernel_policy;
@@ -796,22 +826,26 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // tile geometry: a shape-specialised kernel dictates G; otherwise pick G for LDS / lane use
     uint32_t G = 1, raw_elems = 0;
     const uint32_t T_lds = p->T + p->tile_extra;     // LDS sizing sees the extended tile
-    if (lds_for(1, p->W, p->S, p->D, T_lds, &raw_elems) > kLdsMax)
+    if (lds_for(1, p->W, p->S, p->D, T_lds, &raw_elems, 1, 1, d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8) > kLdsMax)
         return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
                     (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
     p->fixed = (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC) ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
     // qd_plan_options.tile_hint = {G, NT, FIRR, FIRB, LB, PAD}: force a plan-time build with this tiling instead of the table /
     // heuristics (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256; PAD = LDS pad elements per row)
-    uint32_t tune[6] = {0, 0, 1, 8, 4, 1};
+    // [6] = tiles per FFT batch (FixedGeo::kBatch), [7] = workgroups per CU (0: as many as LDS / registers admit, at most 4)
+    const bool lut8 = d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8;
+    uint32_t tune[8] = {0, 0, 1, 8, 4, 1, 1, 0};
+    uint32_t hint_flags = 0;
     bool tuned = false;
     if (p->opt.tile_hint[0] || p->opt.tile_hint[1]) {
         const uint32_t *h = p->opt.tile_hint;
-        const uint32_t t6[6] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u};
-        if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t6[4] >= 1 && t6[4] <= 8 && t6[0] >= 1 &&
-              (t6[1] == 256 || t6[1] == 512 || t6[1] == 1024) && (t6[5] == 1 || t6[5] == 2) &&
-              lds_for(t6[0], p->W, p->S, p->D, T_lds, nullptr, t6[5]) <= kLdsMax))
-            return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u} does not fit this chain", t6[0], t6[1], t6[2], t6[3], t6[4], t6[5]);
-        for (int i = 0; i < 6; ++i) tune[i] = t6[i];
+        const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
+        hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
+        if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 3 &&
+              lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
+            return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
+        for (int i = 0; i < 8; ++i) tune[i] = t8[i];
         tuned = true;
         p->fixed = nullptr;
     }
@@ -822,13 +856,16 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     const bool jit_ok = d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME;
     // a cached build is always used; a NEW build only when forced or when the stream is at least 1 GiB
     const bool may_compile = policy == QD_KERNEL_SPECIALISE || tuned || in_bytes >= (1ull << 30);
-    auto make_key = [&](uint32_t g, int nt, int lb, int noslp, uint32_t padv) {
+    uint32_t batch = 1, kflags = 0;    // tiles per FFT batch / variant flags the main kernel is built with (FixedGeo BATCH_, FLAGS_)
+    if (p->has_fir) { p->taps_h.resize(p->T); design_taps(d.lowpass_hz, d.sample_rate, p->T, p->taps_h.data()); }
+    auto make_key = [&](uint32_t g, int nt, int lb, int noslp, uint32_t padv, uint32_t batchv = 1, uint32_t flagsv = 0) {
         const uint64_t ROW = (uint64_t)nt * spl_of(d.format);
         const uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
         // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
         const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
         return JitKey{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, lb, nt,
-                      p->W, p->S, p->D, p->T, g, tune[3], tune[2], noslp, padv};
+                      p->W, p->S, p->D, p->T, g, tune[3], tune[2], noslp, padv, batchv, flagsv,
+                      (flagsv & kGeoBakedTaps) ? fnv1a(p->taps_h.data(), p->taps_h.size() * sizeof(float)) : 0ull};
     };
     // FIR-dominated shapes (>= 8 taps per input sample): a tile's FIR phase is latency-bound — one wave walks
     // all T taps however few outputs the tile has — so take the largest tile with <= 512 FIR outputs that LDS
@@ -840,7 +877,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (heavy) {
         auto outs = [&](uint32_t g) { return p->S < p->W ? (uint64_t)(g - 1) * p->S + p->W : (uint64_t)g * p->W; };
         uint32_t gh = 1;           // 16-byte aligned LDS rows (pad 2): ds_read_b128 sample pairs in the tap loop (FixedGeo::kPad)
-        while (gh < 64 && outs(gh + 1) <= 512 && lds_for(gh + 1, p->W, p->S, p->D, T_lds, nullptr, 2) <= kLdsMax) ++gh;
+        while (gh < 64 && outs(gh + 1) <= 512 && lds_for(gh + 1, p->W, p->S, p->D, T_lds, nullptr, 2, 1, lut8) <= kLdsMax) ++gh;
         if (p->n_windows && gh > p->n_windows) gh = (uint32_t)p->n_windows;
         p->jit_fn = jit_chain_kernel(make_key(gh, 512, 2, 1, 2), &p->jit_note, may_compile);
         heavy = p->jit_fn != nullptr;                  // else: the default tiling below, on whatever kernel is available
@@ -852,17 +889,20 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         p->nt = (int)tune[1];
         jit_lb = (int)tune[4];
         pad = tune[5];
+        batch = tune[6];
+        kflags = hint_flags;
     } else if (p->fixed) {
         G = p->fixed->G;
         p->nt = p->fixed->nt;
         pad = (uint32_t)p->fixed->pad;
+        batch = (uint32_t)p->fixed->batch;
     } else {
-        while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr) <= 40 * 1024) G *= 2;
-        while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr) <= 36 * 1024) G *= 2;
+        while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
+        while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
         if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
     }
     p->geo.G = G;
-    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad);     // the generic kernels (pad 1) fit inside the same allocation
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
@@ -874,7 +914,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         // plan-time specialisation for shapes without a built-in FixedGeo kernel
         const bool want = !heavy && (tuned || (!p->fixed && jit_ok));
         if (want) {
-            p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad), &p->jit_note, may_compile);
+            p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad, batch, kflags), &p->jit_note, may_compile, &p->taps_h);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "tile_hint build failed: %s", p->jit_note.c_str());
         }
     }
@@ -885,6 +925,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->nt > kThreads) { int by_threads = 2048 / p->nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
     if (tuned || heavy) { int by_regs = (jit_lb * 4 * 64) / p->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
+    if (tuned && tune[7] && (int)tune[7] < p->wg_per_cu) p->wg_per_cu = (int)tune[7];
+    if (const char *e = dev_env("QD_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) p->wg_per_cu = v; }      // development builds
     // Dynamic-LDS limit: the kernels are process-global objects shared by every plan, so the attribute is set to the
     // hardware maximum (160 KiB), never to one plan's tile — a later plan with a smaller tile must not lower the limit
     // under a live plan with a larger one (tests/test_gpu_robustness.py::test_two_live_plans_with_different_lds).
@@ -906,8 +948,6 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         HIPCHK(hipMemcpy(p->tw_d, p->fft.tw.data(), p->fft.tw.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
     if (p->has_fir) {
-        p->taps_h.resize(p->T);
-        design_taps(d.lowpass_hz, d.sample_rate, p->T, p->taps_h.data());
         HIPCHK(hipMalloc(&p->taps_d, p->T * sizeof(float)));
         HIPCHK(hipMemcpy(p->taps_d, p->taps_h.data(), p->T * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -1415,7 +1455,7 @@ int cached_fft_plan(uint64_t W, uint64_t S, int kind, CachedPlan **out) {
     if (kind == 1) {                               // take_fft: one irregular row per tile, per-sample (unaligned) kernel
         p->geo.G = 1;
         uint32_t raw_elems = 0;
-        p->geo.lds_bytes = lds_for(1, p->W, p->S, p->D, p->T, &raw_elems);
+        p->geo.lds_bytes = lds_for(1, p->W, p->S, p->D, p->T, &raw_elems, 1, 1, false);
         p->geo.lds_raw_elems = raw_elems;
         p->fn = p->fn_unaligned;
     }
@@ -1438,7 +1478,7 @@ int cached_fft_plan(uint64_t W, uint64_t S, int kind, CachedPlan **out) {
 }
 
 // ---- Bluestein tables per width (host f64 arithmetic, rounded once to f32), cached per device
-struct BluesteinTab { int device; uint32_t W, M, logM; float2 *chirp, *Bbr, *tw; };
+struct BluesteinTab { int device; uint32_t W, M, logM; double2 *chirp, *Bbr, *tw; };
 std::mutex g_bt_mu;
 std::vector<BluesteinTab> g_bt;
 
@@ -1470,13 +1510,13 @@ int bluestein_tab(uint32_t W, BluesteinTab *out) {
     t.device = dev; t.W = W;
     t.logM = ilog2(2ull * W - 1); t.M = 1u << t.logM;
     const uint32_t M = t.M;
-    std::vector<float2> chirp(W), Bbr(M), tw(M / 2 ? M / 2 : 1);
+    std::vector<double2> chirp(W), Bbr(M), tw(M / 2 ? M / 2 : 1);
     std::vector<double> br(M, 0.0), bi(M, 0.0);
     for (uint32_t n = 0; n < W; ++n) {
         const uint64_t q = ((uint64_t)n * n) % (2ull * W);       // n^2 mod 2W: the angle is reduced exactly, in integers
         const double ang = kPi64 * (double)q / (double)W;
         const double cr = std::cos(ang), ci = std::sin(ang);     // b[n] = e^{+i pi n^2 / W}
-        chirp[n] = make_float2((float)cr, (float)-ci);            // c[n] = conj(b[n])
+        chirp[n] = make_double2(cr, -ci);                         // c[n] = conj(b[n])
         br[n] = cr; bi[n] = ci;
         if (n) { br[M - n] = cr; bi[M - n] = ci; }
     }
@@ -1484,17 +1524,17 @@ int bluestein_tab(uint32_t W, BluesteinTab *out) {
     for (uint32_t r = 0; r < M; ++r) {
         uint32_t k = 0;
         for (uint32_t b = 0; b < t.logM; ++b) if (r & (1u << b)) k |= 1u << (t.logM - 1 - b);
-        Bbr[r] = make_float2((float)(br[k] / (double)M), (float)(bi[k] / (double)M));
+        Bbr[r] = make_double2(br[k] / (double)M, bi[k] / (double)M);
     }
     for (uint32_t k = 0; k < M / 2; ++k) {
         const double ang = -2.0 * kPi64 * (double)k / (double)M;
-        tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        tw[k] = make_double2(std::cos(ang), std::sin(ang));
     }
-    if (M / 2 == 0) tw[0] = make_float2(1.f, 0.f);
-    HIPCHK(hipMalloc(&t.chirp, chirp.size() * 8)); HIPCHK(hipMalloc(&t.Bbr, Bbr.size() * 8)); HIPCHK(hipMalloc(&t.tw, tw.size() * 8));
-    HIPCHK(hipMemcpy(t.chirp, chirp.data(), chirp.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(t.Bbr, Bbr.data(), Bbr.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(t.tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    if (M / 2 == 0) tw[0] = make_double2(1.0, 0.0);
+    HIPCHK(hipMalloc(&t.chirp, chirp.size() * 16)); HIPCHK(hipMalloc(&t.Bbr, Bbr.size() * 16)); HIPCHK(hipMalloc(&t.tw, tw.size() * 16));
+    HIPCHK(hipMemcpy(t.chirp, chirp.data(), chirp.size() * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.Bbr, Bbr.data(), Bbr.size() * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice));
     if (g_bt.size() >= 64) {                                      // the width slider walks through many lengths: bound the cache
         (void)hipDeviceSynchronize();
         (void)hipFree(g_bt[0].chirp); (void)hipFree(g_bt[0].Bbr); (void)hipFree(g_bt[0].tw);
@@ -1507,13 +1547,13 @@ int bluestein_tab(uint32_t W, BluesteinTab *out) {
 
 int bluestein_rows(const float2 *src, uint64_t in_first, const uint64_t *offs_d, const float *win_d, size_t W, size_t n_rows,
                    float *dst, hipStream_t st) {
-    if (W > 8192) return fail(QD_ERR_UNSUPPORTED, "take_fft width %zu: widths that are not a power of two are built up to 8192", W);
+    if (W > 4096) return fail(QD_ERR_UNSUPPORTED, "take_fft width %zu: widths that are not a power of two are built up to 4096 (the reference front end's slider range, src/eui/mod.rs:157)", W);
     BluesteinTab t{};
     int rc = bluestein_tab((uint32_t)W, &t);
     if (rc) return rc;
-    if ((size_t)t.M * 8 > 48 * 1024)      // per device, cheap: raise the dynamic-LDS limit to the hardware maximum
+    if ((size_t)t.M * 16 > 48 * 1024)     // per device, cheap: raise the dynamic-LDS limit to the hardware maximum
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bluestein), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-    hipLaunchKernelGGL(k_bluestein, dim3((uint32_t)n_rows), dim3(256), (size_t)t.M * 8, st, src, in_first, offs_d, win_d, (uint32_t)W, t.M, t.logM,
+    hipLaunchKernelGGL(k_bluestein, dim3((uint32_t)n_rows), dim3(256), (size_t)t.M * 16, st, src, in_first, offs_d, win_d, (uint32_t)W, t.M, t.logM,
                        t.chirp, t.Bbr, t.tw, dst);
     HIPCHK(hipGetLastError());
     return QD_OK;
@@ -1596,7 +1636,7 @@ int qd_shift(qd_c32 *buf, size_t n, uint64_t abs_off, double ratio, int mem) {
     rc = ws.get(3, ROW * sizeof(double2), &jt); if (rc) return rc;
     hipLaunchKernelGGL(k_rowtab, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, st, ratio, ROW, r0, rows, static_cast<RowBase *>(rt));
     hipLaunchKernelGGL(k_jtab, dim3(2), dim3(256), 0, st, ratio, ROW, static_cast<double2 *>(jt));
-    const int so = (std::fabs(ratio) * (double)(abs_off + n) > 134217728.0) ? 1 : 0;
+    const int so = (std::fabs(ratio) * (double)(abs_off + n) > 268435456.0) ? 1 : 0;
     const uint32_t grid = (uint32_t)(rows < 4096 ? rows : 4096);
     hipLaunchKernelGGL(k_shift, dim3(grid), dim3(256), 0, st, d, abs_off, (uint64_t)n, ratio, static_cast<const RowBase *>(rt), r0, rows,
                        static_cast<const double2 *>(jt), so);

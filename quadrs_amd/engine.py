@@ -126,7 +126,7 @@ def options_from_env(**overrides):
     """Harness convenience (tests, bench.py, scripts/): the library itself reads no tuning environment variables, so the
     knobs the test matrix is run under are translated HERE into an explicit qd_plan_options —
     QD_NO_FIXED=1 -> QD_KERNEL_GENERIC, QD_JIT=1 / 0 -> QD_KERNEL_SPECIALISE / QD_KERNEL_NO_PLAN_TIME,
-    QD_TUNE=G:NT:FIRR:FIRB:LB:PAD -> tile_hint, QD_NCO_ORDER, QD_CHUNK_MB, QD_COPY_THREADS."""
+    QD_TUNE=G:NT:FIRR:FIRB:LB:PAD:BATCH:WG_PER_CU -> tile_hint, QD_NCO_ORDER, QD_CHUNK_MB, QD_COPY_THREADS."""
     e = os.environ
     kw = dict(kernel_policy=_ffi.KERNEL_AUTO)
     if e.get("QD_NO_FIXED"):
@@ -136,7 +136,7 @@ def options_from_env(**overrides):
     elif e.get("QD_JIT") == "0":
         kw["kernel_policy"] = _ffi.KERNEL_NO_PLAN_TIME
     if e.get("QD_TUNE") and not e.get("QD_NO_FIXED"):
-        kw["tile_hint"] = [int(v) for v in e["QD_TUNE"].split(":")][:6]
+        kw["tile_hint"] = [int(v) for v in e["QD_TUNE"].split(":")][:8]
     if e.get("QD_NCO_ORDER") in ("1", "2"):
         kw["nco_order"] = int(e["QD_NCO_ORDER"])
     if e.get("QD_CHUNK_MB"):

@@ -83,7 +83,7 @@ def test_product_never_imports_oracle():
 def test_options_struct_and_validation(engine):
     """qd_plan_options is checked before any GPU call; sizes match the header's layout."""
     from quadrs_amd import _ffi
-    assert C.sizeof(_ffi.PlanOptions) == 4 * 4 + 8 + 4 + 16 * 4 + 6 * 4 + 4 and C.sizeof(_ffi.ShardInfo) == 48 and C.sizeof(_ffi.PlanStats) == 40
+    assert C.sizeof(_ffi.PlanOptions) == 4 * 4 + 8 + 4 + 16 * 4 + 8 * 4 + 4 and C.sizeof(_ffi.ShardInfo) == 48 and C.sizeof(_ffi.PlanStats) == 40
     kw = dict(fmt=engine.FMT_CF32, sample_rate=21_000_000, n_samples=1 << 20, width=128)
     for bad in (dict(kernel_policy=9), dict(nco_order=3), dict(copy_threads=1000), dict(chunk_bytes=10)):
         with pytest.raises(engine.QuadrsError) as ei:
@@ -113,3 +113,20 @@ def test_shipped_library_reads_no_tuning_environment(engine):
     strings = subprocess.run(["strings", "-a", engine._ffi.LIB_PATH], capture_output=True, text=True).stdout
     for knob in ("QD_DEBUG_SKIP", "QD_TUNE", "QD_JIT_FLAGS", "QD_WG_PER_CU", "QD_NO_FIXED", "QD_CHUNK_MB"):
         assert knob not in strings, knob
+
+
+def test_builtin_kernels_do_not_spill(engine):
+    """hipcc's per-kernel resource remarks of the build that produced the library (build/kernel_resources.json): the
+    shape-specialised chain kernels keep their arithmetic in registers.  A scheduling accident here is silent and ruinous —
+    the 200-tap kernel once spilled every FIR product (185 VGPRs of scratch) and ran 8.7x slower with parity still green."""
+    import json
+    from quadrs_amd import build as B
+    if not os.path.exists(B.RESOURCES) or os.path.getmtime(B.RESOURCES) < os.path.getmtime(B.OUT) - 600:
+        B.build(force=True)
+    res = json.load(open(B.RESOURCES))
+    fixed = {k: v for k, v in res.items() if "k_chain" in k and "FixedGeo" in k}
+    assert len(fixed) >= 8, sorted(res)
+    bad = {k: v for k, v in fixed.items() if v.get("VGPRs Spill", 0) > 2 or v.get("ScratchSize", 0) > 16}
+    assert not bad, bad
+    generic = {k: v for k, v in res.items() if "k_chain" in k and "DynGeo" in k}
+    assert generic and all(v.get("ScratchSize", 0) <= 256 for v in generic.values()), {k: v for k, v in generic.items() if v.get("ScratchSize", 0) > 256}

