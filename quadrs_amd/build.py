@@ -20,7 +20,10 @@ OUT = os.path.join(HERE, "libquadrs_hip.so")
 
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"),
-         "-Rpass-analysis=kernel-resource-usage"]
+         "-Rpass-analysis=kernel-resource-usage",
+         # the tile queue's claim is ONE lane's atomic whose reply is read a phase later; LLVM's atomic optimizer would
+         # rewrite it into a wave reduction + readfirstlane behind an immediate s_waitcnt vmcnt(0) (a full drain of the prefetch)
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 # per-kernel register / scratch figures of the last build (hipcc's kernel-resource-usage remarks), audited by
 # tests/test_abi_cpu.py::test_builtin_kernels_do_not_spill: a scheduling accident that spills the FIR's products costs 8x
 RESOURCES = os.path.join(ROOT, "build", "kernel_resources.json")
@@ -128,10 +131,12 @@ def build_dev(verbose=False, extra=()):
         cmd = [hipcc()] + FLAGS + more + ["-DQD_DEVELOP"] + list(extra) + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, subprocess.Popen(cmd)))
+        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
         objs.append(obj)
     for cmd, pr in procs:
-        if pr.wait() != 0:
+        _, err = pr.communicate()
+        if pr.returncode != 0:
+            print(err, file=sys.stderr)
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_OUT] + objs + ["-lhiprtc", "-ldl"])
     return DEV_OUT

@@ -95,6 +95,8 @@ struct ChainParams {
     float gstep;               // glyph epilogue: (rmax - rmin) / 7.0f, computed on the host (see glyph_code)
     uint32_t dbg;              // development builds (-DQD_DEVELOP) only: timing-only ablation bits (1 NCO, 2 FIR, 4 FFT, 8 hypot, 16 output store, 32 LDS staging); else only the never-true liveness sentinel reads it
     unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
+    unsigned long long *work;   // dynamic tile queue: 8 per-XCD-group counters + 1 arrival counter, 16 words (128 B) apart, all zero
+                                // at launch (the last workgroup to finish zeroes them again); NULL: static strided walk
     const uint64_t *row_offsets; // take_fft (src/ffts.rs:59-60): window w starts at row_offsets[w] (generic kernels, G = 1)
     const float *window;         // take_fft windowing (src/ffts.rs:64-68): sample k of a window is scaled by window[k]
     uint32_t blk_len;            // length B of the read_at block the truncation is relative to (== W except QD_EPI_CF32_BLOCKS)
@@ -136,7 +138,7 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
     return ((tile_raw / D + 1) * ct_planar_pitch(D) + 7) & ~7u;
 }
 
-constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2;       // FixedGeo FLAGS_ bits
+constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4;       // FixedGeo FLAGS_ bits
 
 template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1, uint32_t BATCH_ = 1,
           uint32_t FLAGS_ = 0>
@@ -192,7 +194,7 @@ struct FixedGeo {
     static constexpr bool kShared = T_ > 0 && S_ < W_ && kNtrunc <= S_;     // shared-FIR mode (see phase 2)
     // component-split FIR (fir_comp): mid-length filters whose tile leaves at least half the lanes without an output
     static constexpr bool split_ok(uint32_t nt) {
-        return !kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * G_ * W_ <= nt;
+        return !(FLAGS_ & kGeoNoSplit) && !kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * G_ * W_ <= nt;
     }
     // register-tiled kernels: spare waves take the truncated tails (fir_prefix) when main lanes fill whole waves
     static constexpr bool helper_ok(uint32_t nt) {
@@ -203,6 +205,9 @@ struct FixedGeo {
         return kShared && kFirTile == 1 && kPad != 2 && D_ % 8 == 0 && T_ >= 64 && 2u * ((G_ - 1) * S_ + W_) <= nt;
     }
     // the planar layout serves the component-split FIR of non-overlapping-window tiles (every 256-thread shape that asks for it)
+    // packed lane-per-output FIR (fir_pair): FLAGS_ bit 2 on a 16-byte-row tile
+    static constexpr bool kPairFir = (FLAGS_ & kGeoNoSplit) && !kShared && kFirTile == 1 && kPad == 2 && T_ % 4 == 0 && ((T_ - T_ / 2) % D_) % 2 == 0 &&
+                                     D_ % 4 == 0 && T_ >= 32;
     static constexpr bool kPlanar = planar_geometry && split_ok(256u);
     static constexpr bool kBakedTaps = baked_request && kPlanar;       // only the planar FIR takes its taps as immediates
     static constexpr uint32_t lds_raw_elems = kPlanar ? plane_floats : lds_raw_elems_std;      // float2 elements
@@ -212,7 +217,7 @@ struct DynGeo {
     static constexpr bool kFixed = false;
     static constexpr uint32_t kBatch = 1;
     static constexpr uint32_t kFlags = 0;
-    static constexpr bool kPlanar = false, kBakedTaps = false;
+    static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false;
     static constexpr uint32_t DpP = 0, plane_floats = 0;
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
@@ -868,6 +873,54 @@ __device__ __forceinline__ float fir_comp_planar(const float *xp, uint32_t jmax,
     return jmax < T ? snap : acc;
 }
 
+// Packed lane-per-output FIR (FixedGeo FLAGS_ bit 2, interleaved tile with 16-byte aligned rows, PAD 2): a lane carries BOTH
+// accumulate chains of one output as a float pair and advances them with one v_pk_mul_f32 + one v_pk_add_f32 per tap —
+// the same two separately rounded operations per component as the scalar form (src/filter.rs:119), half the VALU
+// instructions.  On gfx950 a packed op occupies the pipe as long as two scalar ones, but the chain kernel is bound by
+// issue slots, not by pipe time: the component-split FIR issues 4 VALU instructions per tap and output, this one 2.  Only
+// G*W lanes take part (half the workgroup at G*W = 128).  Two taps (re, im, re, im) come with each ds_read_b128.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <class GeoT>
+__device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row of the output */, uint32_t jmax, const float *h) {
+    constexpr uint32_t D = GeoT::D, Dp = GeoT::Dp, T = GeoT::T, b = GeoT::b0, NB = T / 4;     // blocks of 4 taps = two b128 sample reads
+    constexpr int PF = 3;
+    static_assert(GeoT::kPad == 2 && T % 4 == 0 && b % 2 == 0 && D % 4 == 0 && NB > (uint32_t)PF, "packed FIR geometry");
+    v2f acc = {0.f, 0.f}, snap = {0.f, 0.f};
+    auto cand = [&](uint32_t jj) -> bool { return jj >= T / 2 + D && jj < T && ((jj - T / 2) % D) == 0; };
+    auto xoff = [&](uint32_t t) -> uint32_t { return (t / D) * Dp + (t % D); };      // float2 elements
+    float4 xa[PF], xb[PF], hh[PF];
+    auto load = [&](uint32_t k, int slot) {
+        const uint32_t t0 = b + 4 * k;                      // taps 4k..4k+3; pairs (4k, 4k+1) and (4k+2, 4k+3) never straddle a row (D % 4 == 0, b even... b % 4 may be 2)
+        xa[slot] = *reinterpret_cast<const float4 *>(rowp + xoff(t0));
+        xb[slot] = *reinterpret_cast<const float4 *>(rowp + xoff(t0 + 2));
+        if constexpr (!GeoT::baked_request) hh[slot] = *reinterpret_cast<const float4 *>(h + 4 * k);
+    };
+    auto tap = [&](uint32_t jj, int slot, int i) -> float {
+        if constexpr (GeoT::baked_request) return kBakedTapTable[jj < sizeof(kBakedTapTable) / sizeof(float) ? jj : 0];
+        else return i == 0 ? hh[slot].x : (i == 1 ? hh[slot].y : (i == 2 ? hh[slot].z : hh[slot].w));
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load(k, k);
+#pragma unroll
+    for (uint32_t k = 0; k < NB; ++k) {
+        const int slot = (int)(k % PF);
+        const v2f xs[4] = {{xa[slot].x, xa[slot].y}, {xa[slot].z, xa[slot].w}, {xb[slot].x, xb[slot].y}, {xb[slot].z, xb[slot].w}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t jj = 4 * k + i;
+            if (cand(jj)) { if (jmax == jj) snap = acc; }
+            const float hv = tap(jj, slot, i);
+            const v2f hs = {hv, hv};
+            acc = acc + xs[i] * hs;                        // (re, im) * h, then +=: one v_pk_mul_f32, one v_pk_add_f32
+        }
+        asm volatile("" : "+v"(acc));                       // pin the add chain inside its block (see fir_comp)
+        if (k + PF < NB) load(k + PF, slot);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const v2f r = jmax < T ? snap : acc;
+    return make_float2(r.x, r.y);
+}
+
 // Truncated tail outputs on spare lanes (register-tiled kernels whose workgroup has idle waves in the FIR phase):
 // the reference's per-read_at truncation makes the last kNtrunc outputs of a window PREFIXES of the full chain
 // (jmax = T/2 + m*D taps).  Computing them as accumulator snapshots inside the main loop makes the one wave that
@@ -939,6 +992,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     float2 *trc = dec + ((geo.G - 1) * geo.S + geo.W);
     // batched FFT: where each parked tile's output goes ({window index relative to out, low / high word; window count})
     uint32_t *bmeta = reinterpret_cast<uint32_t *>(GeoT::kShared ? trc + ((geo.G - 1) * geo.S + geo.W) : dec);
+    uint32_t *wq = bmeta + 4 * kBatch;                         // tile queue hand-over: {tile lo, hi} x 2
 
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
@@ -984,15 +1038,49 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     // XCD walks one contiguous eighth of the tile range: its workgroups sit on neighbouring tiles at the same
     // time and the shared rows are L2 hits instead of a second HBM fetch.
     uint64_t walk_base = 0, walk_local = blockIdx.x, walk_step = gridDim.x, walk_limit = n_tiles;
-    if ((gridDim.x & 7u) == 0 && n_tiles >= 8) {
-        const uint64_t n8 = (n_tiles + 7) / 8;
+    const bool xcd_walk = (gridDim.x & 7u) == 0 && n_tiles >= 8;
+    const uint64_t n8 = (n_tiles + 7) / 8;
+    auto xcd_limit = [&](uint32_t x) -> uint64_t { const uint64_t b = (uint64_t)x * n8; return b >= n_tiles ? 0 : (n_tiles - b < n8 ? n_tiles - b : n8); };
+    if (xcd_walk) {
         walk_base = (uint64_t)(blockIdx.x & 7u) * n8;
         walk_local = blockIdx.x >> 3;
         walk_step = gridDim.x >> 3;
-        walk_limit = walk_base >= n_tiles ? 0 : (n_tiles - walk_base < n8 ? n_tiles - walk_base : n8);
+        walk_limit = xcd_limit(blockIdx.x & 7u);
     }
     auto walk_tile = [&](uint64_t local) -> uint64_t { return local < walk_limit ? walk_base + local : n_tiles; };   // n_tiles = none
-    uint64_t tile = walk_tile(walk_local);
+    // Dynamic tile queue (P.work): instead of a fixed stride, a workgroup CLAIMS its tiles — one atomic add on the counter of
+    // its XCD group's eighth of the tile range, issued a tile ahead so the reply is never waited for, and on the other
+    // groups' counters once its own eighth is exhausted.  Workgroups of one XCD still sit on neighbouring tiles (shared halo
+    // rows are L2 hits), but none idles while another still has a backlog: with the static walk the fastest workgroups
+    // finish at 80 % of the kernel's span (per-CU and per-XCD speed differs by a few %) and ~10 % of the chip-time is lost.
+    const bool dyn = P.work != nullptr && xcd_walk;
+    const uint32_t my_x = blockIdx.x & 7u;
+    auto claim_resolve = [&](unsigned long long got) -> uint64_t {        // one lane; `got` = reply of the add on the own counter
+        if (got < xcd_limit(my_x)) return (uint64_t)my_x * n8 + got;
+        for (uint32_t k = 1; k < 8; ++k) {                                // own eighth exhausted: help the others
+            const uint32_t xx = (my_x + k) & 7u;
+            const uint64_t lim = xcd_limit(xx);
+            if (lim == 0) continue;
+            const unsigned long long i = atomicAdd(&P.work[16 * xx], 1ull);
+            if (i < lim) return (uint64_t)xx * n8 + i;
+        }
+        return n_tiles;
+    };
+    uint64_t tile, tile_n;                                                // this tile and the next one (wave-uniform)
+    if (dyn) {
+        if (tid == 0) {
+            const uint64_t a = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
+            const uint64_t b = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
+            wq[0] = (uint32_t)a; wq[1] = (uint32_t)(a >> 32); wq[2] = (uint32_t)b; wq[3] = (uint32_t)(b >> 32);
+        }
+        __syncthreads();
+        tile = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
+        tile_n = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[3]) << 32) | __builtin_amdgcn_readfirstlane(wq[2]);
+        __syncthreads();                                                  // wq is rewritten inside the loop
+    } else {
+        tile = walk_tile(walk_local);
+        tile_n = walk_tile(walk_local + walk_step);
+    }
     TileGeo tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
     Vec pf[RCH];
     if (tg.valid) {
@@ -1000,6 +1088,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, NT, ALIGNED>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
     }
 
+#ifdef QD_WGTIME       // diagnostic build: when each workgroup started / finished (100 MHz realtime counter) and on which XCD
+    unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     double rt_touch = 0.0;   // keeps the row-table L2 prefetch loads alive (see prefetch_rowtab)
     uint32_t bslot = 0;      // parked tiles of the current FFT batch (wave-uniform)
     QD_STAMP_DECL
@@ -1020,8 +1111,10 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             asm volatile("" : "+v"(first));          // opaque per tile: the loads are not hoisted out of the tile loop
             load_lane_rot(first);
         }
+        unsigned long long claim = 0;
+        if (dyn && tid == 0) claim = atomicAdd(&P.work[16 * my_x], 1ull);     // the tile after next; the reply is read after the FIR
         if constexpr (WHOLE) {
-            TileGeo ng = tile_geo<FMT, NT>(P, geo, walk_tile(walk_local + walk_step), n_tiles);
+            TileGeo ng = tile_geo<FMT, NT>(P, geo, tile_n, n_tiles);
             if (!ng.valid) ng = tg;                  // last tile of this workgroup: harmless re-loads
             rt_pf = prefetch_rowtab<HAS_SHIFT>(P, ng, tid);
             RowBase rb_next{};
@@ -1062,7 +1155,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 TileGeo ng = tg;
                 uint32_t rbase = r + RCH;
                 if (rbase >= tg.n_rows) {
-                    const TileGeo t2 = tile_geo<FMT, NT>(P, geo, walk_tile(walk_local + walk_step), n_tiles);
+                    const TileGeo t2 = tile_geo<FMT, NT>(P, geo, tile_n, n_tiles);
                     if (t2.valid) { ng = t2; rbase = 0; rt_pf = prefetch_rowtab<HAS_SHIFT>(P, t2, tid); } else { rbase = tg.n_rows - 1; }
                 }
 #pragma unroll
@@ -1242,6 +1335,16 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 }
             }
         } else
+        if constexpr (HAS_FIR && GeoT::kPairFir) {
+            for (uint32_t o = tid; o < n_out; o += NT) {
+                const uint32_t g = o >> logW, k = o & (W - 1);
+                uint32_t jmax = (W - k) * D + T / 2;
+                if (jmax > T) jmax = T;
+                const float2 v = fir_pair<GeoT>(raw + (size_t)(g * S + k + geo.a0) * Dp, jmax, tapl);
+                const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
+            }
+        } else
         if constexpr (!GeoT::kFixed || !GeoT::kShared) if (!shared)
         for (uint32_t o = tid; o < n_out; o += NT) {
             const uint32_t g = o >> logW, k = o & (W - 1);
@@ -1286,12 +1389,17 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             }
         }
         ++bslot;
-        walk_local += walk_step;
-        tile = walk_tile(walk_local);
-        const TileGeo tg_next = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
+        if (dyn && tid == 0) {
+            const uint64_t t2 = claim_resolve(claim);
+            wq[0] = (uint32_t)t2; wq[1] = (uint32_t)(t2 >> 32);
+        }
+        const TileGeo tg_next = tile_geo<FMT, NT>(P, geo, tile_n, n_tiles);
         const uint32_t batch_lim = (kBatch > 1 && P.epi != 2 && !cf32_out) ? kBatch : 1u;   // the bucket / write sinks flush every tile
         const bool flush = bslot >= batch_lim || !tg_next.valid;                             // wave-uniform
         __syncthreads();
+        tile = tile_n;
+        if (dyn) tile_n = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
+        else { walk_local += walk_step; tile_n = walk_tile(walk_local + walk_step); }
         QD_STAMP_AT(3);
         if (!flush) { rt_touch += rt_pf; tg = tg_next; QD_STAMP_TILE(); continue; }
         const uint32_t n_slots = bslot;
@@ -1416,7 +1524,21 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         QD_STAMP_TILE();
         tg = tg_next;
     }
+    if (dyn && tid == 0) {       // the last workgroup to leave re-arms the queue for the next launch
+        if (atomicAdd(&P.work[16 * 8], 1ull) == (unsigned long long)gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x <= 8; ++x) P.work[16 * x] = 0;
+        }
+    }
     QD_STAMP_FLUSH();
+#ifdef QD_WGTIME
+    if (P.stamps && tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *w = P.stamps + 256 + 4ull * blockIdx.x;
+        w[0] = wg_t0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = xcc & 0xf; w[3] = 1;
+    }
+#endif
     if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
 }
 

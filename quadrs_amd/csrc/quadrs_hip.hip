@@ -310,8 +310,9 @@ const FixedEntry kFixed[] = {
     QD_FIXED(0, 1, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
     QD_FIXED(0, 2, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
     // north_star target sentence: 200-tap FIR decimate 32 -> 128-pt FFT
-    QD_FIXED(0, 1, 128, 128, 32, 200, 1, 9, true, 4, "cfg3p"),
-    QD_FIXED(0, 2, 128, 128, 32, 200, 1, 9, true, 4, "cfg3p"),
+    // packed lane-per-output FIR on a 16-byte-row tile (FixedGeo FLAGS_ bit 2, PAD 2): half the VALU instructions of the FIR
+    QD_FIXED_F(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 4, "cfg3p"),
+    QD_FIXED_F(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 4, "cfg3p"),
     // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
@@ -409,13 +410,17 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     if (hiprtcCreateProgram(&prog, src.c_str(), "qd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *why = "hiprtcCreateProgram failed"; return nullptr; }
     hiprtcAddNameExpression(prog, name);
     const std::string inc = "-I" + dir;
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str()};
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", inc.c_str(),
+                          "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"};      // see build.py: the tile queue's claim stays one plain atomic
     std::vector<const char *> optv(opts, opts + sizeof opts / sizeof opts[0]);
 #ifdef QD_STAMP
     optv.push_back("-DQD_STAMP");
 #endif
 #ifdef QD_DEVELOP
     optv.push_back("-DQD_DEVELOP");
+#endif
+#ifdef QD_WGTIME
+    optv.push_back("-DQD_WGTIME");
 #endif
     if (k.noslp || dev_env("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");   // scalar f32 accumulate chains (see qd_longfir.hip)
     std::vector<std::string> extra;                          // development: QD_JIT_FLAGS="-mllvm -foo ..." appended verbatim
@@ -523,8 +528,8 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     // *raw_elems is what the runtime-geometry kernels read (ChainParams::lds_raw_elems): THEIR raw tile, whatever the main kernel's
     if (raw_elems) *raw_elems = (uint32_t)interleaved(1);
     const bool baked = planar && (flags & kGeoBakedTaps);
-    const uint64_t main_b = elems * 8 + (uint64_t)batch * G * W * 8 + W * 8 + (baked ? 0 : taps_b) + lut_b + shared_fir + (uint64_t)batch * 16;
-    const uint64_t generic_b = interleaved(1) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16;
+    const uint64_t main_b = elems * 8 + (uint64_t)batch * G * W * 8 + W * 8 + (baked ? 0 : taps_b) + lut_b + shared_fir + (uint64_t)batch * 16 + 16;
+    const uint64_t generic_b = interleaved(1) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16 + 16;
     return (size_t)(main_b > generic_b ? main_b : generic_b);
 }
 
@@ -544,7 +549,10 @@ struct RowTab {
 };
 // tables one launch context needs: the main kernel's rows and, for plans whose main kernel is not 256 threads wide,
 // rows laid out for the 256-thread per-sample kernel that takes the windows at an unaligned slab end
-struct NcoTabs { RowTab main, tail; };
+struct NcoTabs {
+    RowTab main, tail;
+    unsigned long long *work = nullptr;      // the launch context's tile-queue counters (ChainParams::work), zero between launches
+};
 
 struct qd_plan {
     qd_chain_desc d{};
@@ -619,6 +627,13 @@ int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowTab *t, uint64_t n_lo, uint64
     return QD_OK;
 }
 
+int ensure_work(NcoTabs *tabs) {
+    if (tabs->work) return QD_OK;
+    HIPCHK(hipMalloc(&tabs->work, 9 * 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(tabs->work, 0, 9 * 16 * sizeof(unsigned long long)));       // the kernel leaves them zero again
+    return QD_OK;
+}
+
 void free_rowtab(RowTab *t) {
     if (t->d) (void)hipFree(t->d);
     *t = RowTab{};
@@ -670,10 +685,11 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     P.blk_len = p->blk_len ? p->blk_len : p->W; P.blk_sub_mask = p->blk_subs - 1;
     P.tile_extra = p->tile_extra;
     P.dbg = p->dbg;                                       // 0 except in development builds (QD_DEBUG_SKIP at plan creation)
-#ifdef QD_STAMP
+#if defined(QD_STAMP) || defined(QD_WGTIME)
+    constexpr size_t kStampWords = 256 + 4 * 4096;
     static unsigned long long *stamps_d = nullptr;
-    if (!stamps_d) { HIPCHK(hipMalloc(&stamps_d, 160 * 8)); }
-    HIPCHK(hipMemsetAsync(stamps_d, 0, 160 * 8, st));
+    if (!stamps_d) { HIPCHK(hipMalloc(&stamps_d, kStampWords * 8)); }
+    HIPCHK(hipMemsetAsync(stamps_d, 0, kStampWords * 8, st));
     P.stamps = stamps_d;
 #endif
 
@@ -709,6 +725,9 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         if (part == 1 && tail_tables) { P.rowtab = tabs->tail.d; P.rowtab_row0 = tabs->tail.row0; P.jtab = p->jtab256_d; }
         const uint64_t n_tiles = (w_count + P.G - 1) / P.G;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
+        // dynamic tile queue for the main launch (static strided walk for the short unaligned tail and for tiny grids)
+        P.work = nullptr;
+        if (part == 0 && (grid & 7u) == 0 && n_tiles >= 4ull * grid) { rc = ensure_work(tabs); if (rc) return rc; P.work = tabs->work; }
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
             void *args[] = {&P};
             HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->nt, 1, 1, (unsigned)p->geo.lds_bytes, st, args, nullptr));
@@ -718,6 +737,27 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         }
     }
     if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
+#ifdef QD_WGTIME
+    {
+        std::vector<unsigned long long> h(kStampWords);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(h.data(), P.stamps, kStampWords * 8, hipMemcpyDeviceToHost));
+        std::vector<double> dur, endt; unsigned long long t_first = ~0ull, t_last = 0; double per_xcc[16] = {0}; int n_xcc[16] = {0};
+        for (int b = 0; b < 4096; ++b) { const unsigned long long *w = &h[256 + 4 * b]; if (!w[3]) continue; t_first = std::min(t_first, w[0]); t_last = std::max(t_last, w[1]); }
+        for (int b = 0; b < 4096; ++b) {
+            const unsigned long long *w = &h[256 + 4 * b]; if (!w[3]) continue;
+            dur.push_back((w[1] - w[0]) * 0.01); endt.push_back((w[1] - t_first) * 0.01); per_xcc[w[2] & 15] += (w[1] - t_first) * 0.01; n_xcc[w[2] & 15]++;
+        }
+        std::sort(dur.begin(), dur.end()); std::sort(endt.begin(), endt.end());
+        if (!dur.empty()) {
+            fprintf(stderr, "[wgtime] %zu workgroups, kernel span %.1f us; workgroup run time us: min %.1f median %.1f max %.1f; finish time us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f\n",
+                    dur.size(), (t_last - t_first) * 0.01, dur.front(), dur[dur.size() / 2], dur.back(), endt.front(), endt[endt.size() / 10], endt[endt.size() / 2], endt[endt.size() * 9 / 10], endt.back());
+            fprintf(stderr, "[wgtime] mean finish time per XCD:");
+            for (int x = 0; x < 16; ++x) if (n_xcc[x]) fprintf(stderr, " xcc%d(%d wgs)=%.1f", x, n_xcc[x], per_xcc[x] / n_xcc[x]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 #ifdef QD_STAMP
     {
         unsigned long long h[160];
@@ -842,7 +882,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 3 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 7 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -896,6 +936,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         p->nt = p->fixed->nt;
         pad = (uint32_t)p->fixed->pad;
         batch = (uint32_t)p->fixed->batch;
+        kflags = (uint32_t)p->fixed->flags;
     } else {
         while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
         while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
@@ -1086,7 +1127,7 @@ int qd_plan_destroy(qd_plan *p) {
     if (p->tw_d) (void)hipFree(p->tw_d);
     if (p->jtab_d) (void)hipFree(p->jtab_d);
     if (p->jtab256_d) (void)hipFree(p->jtab256_d);
-    for (NcoTabs *t : {&p->tabs_dev, &p->tabs_slot[0], &p->tabs_slot[1]}) { free_rowtab(&t->main); free_rowtab(&t->tail); }
+    for (NcoTabs *t : {&p->tabs_dev, &p->tabs_slot[0], &p->tabs_slot[1]}) { free_rowtab(&t->main); free_rowtab(&t->tail); if (t->work) (void)hipFree(t->work); t->work = nullptr; }
     if (p->ev_made) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
     delete p;
     return QD_OK;
