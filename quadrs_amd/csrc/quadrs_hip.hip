@@ -311,8 +311,9 @@ const FixedEntry kFixed[] = {
     QD_FIXED(0, 2, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
     // north_star target sentence: 200-tap FIR decimate 32 -> 128-pt FFT
     // packed lane-per-output FIR on a 16-byte-row tile (FixedGeo FLAGS_ bit 2, PAD 2): half the VALU instructions of the FIR
-    QD_FIXED_F(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 4, "cfg3p"),
-    QD_FIXED_F(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 4, "cfg3p"),
+    // + row-aligned fast phase 1 (bit 3): buffer loads with a per-tile descriptor, compile-time row offsets
+    QD_FIXED_F(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 12, "cfg3p"),
+    QD_FIXED_F(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 12, "cfg3p"),
     // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
@@ -574,6 +575,7 @@ struct qd_plan {
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
     int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0, nt = kThreads;
+    uint32_t kflags = 0;                 // FixedGeo FLAGS_ of the main kernel
     uint32_t dbg = 0;                    // development builds: ablation bits, read once at plan creation
     // NCO tables: lane tables per plan, row tables per launch context (device path; one per slot of the host ring)
     double2 *jtab_d = nullptr, *jtab256_d = nullptr;
@@ -705,6 +707,8 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         const uint64_t usable = (src_count / spl) * spl + src_first;     // end of the last whole vector
         n_aligned = n_windows;
         while (n_aligned > 0 && (first_window + n_aligned - 1) * step + rpw > usable) --n_aligned;
+        // the fast phase 1 (FixedGeo FLAGS_ bit 3) takes whole tiles only: a short last tile goes to the per-sample kernel
+        if ((p->kflags & kGeoFastP1) && (p->jit_fn || p->fixed)) n_aligned -= n_aligned % p->geo.G;
     }
     const bool tail_tables = n_aligned < n_windows && p->nt != kThreads && p->has_shift;
     if (tail_tables) {
@@ -882,7 +886,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 7 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 15 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -943,6 +947,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
     }
     p->geo.G = G;
+    p->kflags = kflags;
     p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
@@ -957,6 +962,13 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         if (want) {
             p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad, batch, kflags), &p->jit_note, may_compile, &p->taps_h);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "tile_hint build failed: %s", p->jit_note.c_str());
+        }
+        // A built-in packed-FIR kernel re-specialised with the plan's OWN filter baked in (taps as immediates: no LDS reads, no
+        // registers for them; +2-3 % on the 16 GiB stream): worth a compile only for streams of several GiB, falls back silently.
+        if (!want && !heavy && !tuned && p->fixed && jit_ok && (p->fixed->flags & kGeoNoSplit) && p->nt == kThreads &&
+            (policy == QD_KERNEL_SPECIALISE || in_bytes >= (4ull << 30))) {
+            JitKey k = make_key(G, p->nt, p->fixed->lb, 0, pad, batch, kflags | kGeoBakedTaps);
+            p->jit_fn = jit_chain_kernel(k, &p->jit_note, true, &p->taps_h);
         }
     }
     hipDeviceProp_t prop;
