@@ -332,6 +332,42 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
     return res
 
 
+def end_to_end_host(device):
+    """Host-resident cfg2 (1 GiB cf32 in host memory -> norms in host memory) through qd_plan_run's chunked, double-buffered
+    path: PCIe-inclusive, reported beside the kernel figures, never as `value`.  Pinned buffers (QD_MEM_HOST_PINNED) are the
+    DMA source / target themselves; the pageable figure stages through a pinned ring with a multi-threaded memcpy."""
+    import numpy as np
+    import torch
+    import quadrs_amd as Q
+    cfg = WORKLOADS["cfg2"]
+    n = cfg["n"]
+    slab = synth_slab(torch, 0, 0, n, 0x5EED0002, device)
+    pin_in = Q.PinnedBuffer(n * 8)
+    torch.cuda.synchronize()
+    pin_in.array[:] = slab.view(torch.uint8).reshape(-1).cpu().numpy()
+    del slab
+    plan = Q.Plan(0, cfg["sr"], n, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
+    out_bytes = plan.n_windows * cfg["W"] * 4
+    pin_out = Q.PinnedBuffer(out_bytes)
+    res = {"workload": "cfg2, host-resident: 1 GiB cf32 in host memory -> fused chain -> norms in host memory", "unit": "GB/s (input bytes / wall)"}
+    for name, pinned in (("pinned", True), ("pageable", False)):
+        src = pin_in.array if pinned else np.array(pin_in.array, copy=True)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            if pinned:
+                plan.run_host(src, pinned=True, out=pin_out.array)
+            else:
+                plan.run_host(src)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        res[name] = {"GBps": n * 8 / best / 1e9, "ms": best * 1e3, "Msamples_per_s": n / best / 1e6}
+    st = plan.stats()
+    res["chunks"] = int(st.chunks)
+    plan.close(); pin_in.close(); pin_out.close()
+    return res
+
+
 def stub_rank(args, rank, world):
     """--stub: the launch / rendezvous / barrier / max-over-ranks skeleton with a sleep for a step, on the CPU (gloo).
     Covers the self-spawn path in the CPU test suite; prints a line that says so."""
@@ -442,6 +478,11 @@ def main():
                 line[k] = main_res[k]
         if others:
             line["others"] = others
+        if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
+            try:
+                line["end_to_end"] = end_to_end_host(device)
+            except Exception as e:                       # the PCIe leg never takes the bench line down
+                line["end_to_end"] = {"error": str(e)[:200]}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -19,6 +19,7 @@
 #include <memory>
 #include <regex>
 #include <string>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
@@ -346,14 +347,49 @@ struct ChainSpec {          // what a fused plan can express
     const Op *src = nullptr, *shift = nullptr, *lowpass = nullptr;
 };
 
-std::vector<uint8_t> slurp(const std::string &fn) {
-    FILE *f = fopen(fn.c_str(), "rb");
-    if (!f) bail(std::string(strerror(errno)) + ": " + fn);
-    std::vector<uint8_t> d;
-    uint8_t buf[1 << 16]; size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
-    fclose(f);
-    return d;
+// The whole source file for a fused plan: mapped, not read — and registered with the HIP runtime when it allows it, so the
+// engine copies straight out of the page cache (QD_MEM_HOST_PINNED) instead of staging every chunk through a pinned ring.
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t size = 0;
+    int mem = QD_MEM_HOST;
+    explicit MappedFile(const std::string &fn) {
+        int fd = open(fn.c_str(), O_RDONLY);
+        if (fd < 0) bail(std::string(strerror(errno)) + ": " + fn);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); bail(std::string(strerror(errno)) + ": " + fn); }
+        size = (size_t)st.st_size;
+        if (size) {
+            void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); bail(std::string(strerror(errno)) + ": " + fn); }
+            p = static_cast<const uint8_t *>(m);
+            if (size >= (64u << 20) && qd_host_register(m, size) == QD_OK) mem = QD_MEM_HOST_PINNED;   // small files: not worth pinning
+        }
+        close(fd);
+    }
+    ~MappedFile() {
+        if (p) {
+            if (mem == QD_MEM_HOST_PINNED) (void)qd_host_unregister(const_cast<uint8_t *>(p));
+            munmap(const_cast<uint8_t *>(p), size);
+        }
+    }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
+
+int g_gpus = 1;      // `-gpus N` in front of the chain: shard the sink's windows over N devices (qd_plan_run_sharded)
+
+// plan for the CLI: the library's defaults, plus window-range shards over g_gpus devices (repeating devices when the
+// machine has fewer: the shards then run as independent streams of one device)
+int create_plan(const qd_chain_desc &d, qd_plan **plan) {
+    if (g_gpus <= 1) return qd_plan_create(&d, plan);
+    qd_plan_options o{};
+    o.struct_size = sizeof o;
+    int n_dev = 1;
+    if (qd_device_count(&n_dev) != QD_OK || n_dev < 1) n_dev = 1;
+    o.n_shards = (uint32_t)(g_gpus > QD_MAX_SHARDS ? QD_MAX_SHARDS : g_gpus);
+    for (uint32_t g = 0; g < o.n_shards; ++g) o.shard_device[g] = (int32_t)(g % (uint32_t)n_dev);
+    return qd_plan_create_ex(&d, &o, plan);
 }
 
 // device buffer that frees itself (the `gen` source of a fused chain lives in HBM)
@@ -366,13 +402,13 @@ struct DeviceBuf {
 // (src/gen.rs:30-47) and never crosses PCIe: only the glyph codes / digits come back
 void run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
     const bool from_gen = cs.src->kind == OP_GEN;
-    std::vector<uint8_t> data;
-    if (!from_gen) data = slurp(cs.src->filename);
+    std::unique_ptr<MappedFile> data;
+    if (!from_gen) data.reset(new MappedFile(cs.src->filename));
     qd_chain_desc d{};
     d.struct_size = sizeof d;
     d.format = from_gen ? QD_FMT_CF32 : cs.src->format; d.sample_rate = cs.src->sample_rate;
     d.n_samples = from_gen ? (uint64_t)(cs.src->seconds * (double)cs.src->sample_rate)          // Gen::len, src/gen.rs:32
-                           : data.size() / qd_pair_bytes(cs.src->format);
+                           : data->size / qd_pair_bytes(cs.src->format);
     if (cs.shift) { d.has_shift = 1; d.shift_hz = cs.shift->shift; }
     if (cs.lowpass) { d.has_lowpass = 1; d.lowpass_hz = cs.lowpass->lp_freq; d.decimate = cs.lowpass->decimate; d.taps = cs.lowpass->size; }
     d.width = sink.width; d.stride = sink.stride;
@@ -380,12 +416,14 @@ void run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
     d.has_range = sink.has_range; d.range_min = sink.rmin; d.range_max = sink.rmax;
     if (sink.kind == OP_SPARKFFT) printf("sparkfft sample_rate=%" PRIu64 "\n", out_rate);   // printed before any read (src/fft.rs:19)
     qd_plan *plan = nullptr;
-    qd_check(qd_plan_create(&d, &plan), "plan");
+    qd_check(from_gen ? qd_plan_create(&d, &plan) : create_plan(d, &plan), "plan");
     qd_plan_info info;
     qd_check(qd_plan_get_info(plan, &info), "plan info");
     std::vector<uint8_t> out(info.n_windows * info.out_bytes_per_window + 1);
-    if (info.n_windows && !from_gen)
-        qd_check(qd_plan_run(plan, data.data(), QD_MEM_HOST, 0, d.n_samples, 0, info.n_windows, out.data(), QD_MEM_HOST, nullptr), "run");
+    if (info.n_windows && !from_gen) {
+        if (g_gpus > 1) qd_check(qd_plan_run_sharded(plan, data->p, data->mem, out.data(), QD_MEM_HOST), "run (sharded)");
+        else qd_check(qd_plan_run(plan, data->p, data->mem, 0, d.n_samples, 0, info.n_windows, out.data(), QD_MEM_HOST, nullptr), "run");
+    }
     if (info.n_windows && from_gen) {
         DeviceBuf src, dst;
         const size_t ob = (size_t)(info.n_windows * info.out_bytes_per_window);
@@ -493,22 +531,23 @@ void do_write(const Samples &s, bool overwrite, const std::string &prefix, const
     uint64_t off = 0, len;
     try { len = s.len(); } catch (...) { close(fd); throw; }
     if (cs && cs->fusable && cs->src->kind == OP_FROM && cs->lowpass && !getenv("QUADRS_HIP_NO_FUSE")) {
-        std::vector<uint8_t> data = slurp(cs->src->filename);
+        MappedFile data(cs->src->filename);
         qd_chain_desc d{};
         d.struct_size = sizeof d;
         d.format = cs->src->format; d.sample_rate = cs->src->sample_rate;
-        d.n_samples = data.size() / qd_pair_bytes(cs->src->format);
+        d.n_samples = data.size / qd_pair_bytes(cs->src->format);
         if (cs->shift) { d.has_shift = 1; d.shift_hz = cs->shift->shift; }
         d.has_lowpass = 1; d.lowpass_hz = cs->lowpass->lp_freq; d.decimate = cs->lowpass->decimate; d.taps = cs->lowpass->size;
         d.width = 0x1000; d.stride = 0x1000; d.epilogue = QD_EPI_CF32_BLOCKS;
         qd_plan *plan = nullptr;
-        int rc = qd_plan_create(&d, &plan);
+        int rc = create_plan(d, &plan);
         if (rc == QD_OK) {
             qd_plan_info info;
             qd_check(qd_plan_get_info(plan, &info), "plan info");
             if (info.n_windows) {
                 std::vector<qd_c32> out(info.n_windows * 0x1000);
-                rc = qd_plan_run(plan, data.data(), QD_MEM_HOST, 0, d.n_samples, 0, info.n_windows, out.data(), QD_MEM_HOST, nullptr);
+                rc = g_gpus > 1 ? qd_plan_run_sharded(plan, data.p, data.mem, out.data(), QD_MEM_HOST)
+                                : qd_plan_run(plan, data.p, data.mem, 0, d.n_samples, 0, info.n_windows, out.data(), QD_MEM_HOST, nullptr);
                 if (rc == QD_OK) {
                     if (write(fd, out.data(), out.size() * sizeof(qd_c32)) < 0) { qd_plan_destroy(plan); close(fd); bail("write failed"); }
                     off = info.n_windows * 0x1000;
@@ -531,7 +570,7 @@ void do_write(const Samples &s, bool overwrite, const std::string &prefix, const
 
 void usage() {
     fprintf(stderr,
-            "usage: quadrs-hip \\\n"
+            "usage: quadrs-hip [-gpus N] \\\n"
             "    from [-sr SAMPLE_RATE] [-format cf32|cs8|cu8|cs16] FILENAME.sr32k.cf32 \\\n"
             "   shift [-]FREQUENCY \\\n"
             " lowpass [-power 20] [-decimate 8] FREQUENCY \\\n"
@@ -547,6 +586,12 @@ void usage() {
 int main(int argc, char **argv) {
     std::vector<std::string> args(argv + 1, argv + argc);
     try {
+        // engine option in front of the reference's grammar: -gpus N shards the sink's windows over N devices in this process
+        if (args.size() >= 2 && args[0] == "-gpus") {
+            g_gpus = atoi(args[1].c_str());
+            if (g_gpus < 1 || g_gpus > QD_MAX_SHARDS) { usage(); fprintf(stderr, "Error: -gpus takes 1..%d\n", QD_MAX_SHARDS); return 2; }
+            args.erase(args.begin(), args.begin() + 2);
+        }
         if (args.empty()) { usage(); return 2; }
         std::vector<Op> ops;
         try { ops = parse(args); } catch (const Fail &f) { usage(); fprintf(stderr, "Error: %s\n", f.msg.c_str()); return 2; }

@@ -140,3 +140,33 @@ def test_gen_source_runs_fused_on_the_device(cli, oracle):
     want = ch.spark_text(16, 8, (0.02, 3.0))
     got = run(cli, *chain, "sparkfft", "-width", "16", "-stride", "8", "-range", "0.02:3").stdout
     assert got.decode() == want if isinstance(want, str) else got == want
+
+
+@pytest.mark.gpu
+def test_gpus_flag_shards_inside_one_process(cli, tmp_path):
+    """`quadrs-hip -gpus N ...`: the sink's windows go over N shards (devices repeat on a one-GPU box) through
+    qd_plan_run_sharded; stdout and written files are byte-identical to the one-device run.  The source file is mapped and,
+    when large enough, registered with the HIP runtime (QD_MEM_HOST_PINNED)."""
+    rng = np.random.default_rng(11)
+    n = 9_000_000                                                     # 72 MB cf32: above the 64 MiB pinning threshold
+    t = np.arange(n)
+    z = 0.02 * np.exp(2j * np.pi * (-280000.0 / 21e6) * t) * np.sign(np.sin(2 * np.pi * 9600.0 / 21e6 * t) + 1e-9)
+    x = np.stack([z.real, z.imag], axis=1).astype(np.float32) + (rng.standard_normal((n, 2)) * 0.002).astype(np.float32)
+    src = tmp_path / "big.sr21M.cf32"
+    x.tofile(src)
+    chain = ["from", str(src), "shift", "280000", "lowpass", "-power", "100", "-decimate", "32", "200000"]
+    one = run(cli, *chain, "sparkfft", "-width", "128", "-range", "0.0005:0.05")
+    assert one.returncode == 0 and one.stdout.count(b"\n") > 2000, one.stderr[-500:]
+    for g in ("2", "3", "8"):
+        r = run(cli, "-gpus", g, *chain, "sparkfft", "-width", "128", "-range", "0.0005:0.05")
+        assert r.returncode == 0 and r.stdout == one.stdout, (g, r.stderr[-500:])
+    r = run(cli, "-gpus", "4", *chain, "bucket", "-width", "64", "-by", "freq", "2")
+    r1 = run(cli, *chain, "bucket", "-width", "64", "-by", "freq", "2")
+    assert r.returncode == 0 and r.stdout == r1.stdout and len(r.stdout) > 1000
+    a = run(cli, *chain, "write", "-overwrite", "yes", str(tmp_path / "one"))
+    b = run(cli, "-gpus", "2", *chain, "write", "-overwrite", "yes", str(tmp_path / "two"))
+    assert a.returncode == b.returncode
+    fa = (tmp_path / "one.sr656250.cf32").read_bytes()
+    assert fa == (tmp_path / "two.sr656250.cf32").read_bytes() and len(fa) > 2_000_000
+    bad = run(cli, "-gpus", "99", *chain, "sparkfft")
+    assert bad.returncode == 2 and b"-gpus takes" in bad.stderr
