@@ -350,18 +350,28 @@ def end_to_end_host(device):
     out_bytes = plan.n_windows * cfg["W"] * 4
     pin_out = Q.PinnedBuffer(out_bytes)
     res = {"workload": "cfg2, host-resident: 1 GiB cf32 in host memory -> fused chain -> norms in host memory", "unit": "GB/s (input bytes / wall)"}
-    for name, pinned in (("pinned", True), ("pageable", False)):
-        src = pin_in.array if pinned else np.array(pin_in.array, copy=True)
+
+    def best_of(p, src, pinned, reps=3):
         best = None
-        for _ in range(3):
+        for _ in range(reps):
             t0 = time.perf_counter()
             if pinned:
-                plan.run_host(src, pinned=True, out=pin_out.array)
+                p.run_host(src, pinned=True, out=pin_out.array)
             else:
-                plan.run_host(src)
+                p.run_host(src)
             dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
-        res[name] = {"GBps": n * 8 / best / 1e9, "ms": best * 1e3, "Msamples_per_s": n / best / 1e6}
+        return best
+    for name, pinned in (("pinned", True), ("pageable", False)):
+        src = pin_in.array if pinned else np.array(pin_in.array, copy=True)
+        best = best_of(plan, src, pinned)
+        res[name] = {"GBps": n * 8 / best / 1e9, "ms": best * 1e3, "Msamples_per_s": n / best / 1e6, "chunk_MiB": 64}
+    sweep = {}
+    for mib in (8, 16, 32, 128):                 # the library's default chunk is 64 MiB: how the pinned path moves with it
+        p2 = Q.Plan(0, cfg["sr"], n, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"], chunk_bytes=mib << 20)
+        sweep[str(mib)] = n * 8 / best_of(p2, pin_in.array, True, reps=2) / 1e9
+        p2.close()
+    res["pinned_GBps_by_chunk_MiB"] = sweep
     st = plan.stats()
     res["chunks"] = int(st.chunks)
     plan.close(); pin_in.close(); pin_out.close()

@@ -138,7 +138,7 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
     return ((tile_raw / D + 1) * ct_planar_pitch(D) + 7) & ~7u;
 }
 
-constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8;       // FixedGeo FLAGS_ bits
+constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32;   // FixedGeo FLAGS_ bits
 
 template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1, uint32_t BATCH_ = 1,
           uint32_t FLAGS_ = 0>
@@ -208,6 +208,8 @@ struct FixedGeo {
     // packed lane-per-output FIR (fir_pair): FLAGS_ bit 2 on a 16-byte-row tile
     static constexpr bool kPairFir = (FLAGS_ & kGeoNoSplit) && !kShared && kFirTile == 1 && kPad == 2 && T_ % 4 == 0 && ((T_ - T_ / 2) % D_) % 2 == 0 &&
                                      D_ % 4 == 0 && T_ >= 32;
+    static constexpr bool kUnrolledShared = (FLAGS_ & kGeoUnrolledFir) && kShared && kFirTile == 1 && kPad == 2 && T_ % 4 == 0 &&
+                                            ((T_ - T_ / 2) % D_) % 2 == 0 && D_ % 4 == 0 && T_ >= 32;
     static constexpr bool kPlanar = planar_geometry && split_ok(256u);
     static constexpr bool kBakedTaps = baked_request && kPlanar;       // only the planar FIR takes its taps as immediates
     static constexpr uint32_t lds_raw_elems = kPlanar ? plane_floats : lds_raw_elems_std;      // float2 elements
@@ -217,7 +219,7 @@ struct DynGeo {
     static constexpr bool kFixed = false;
     static constexpr uint32_t kBatch = 1;
     static constexpr uint32_t kFlags = 0, G_ct = 1;
-    static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false;
+    static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false, kUnrolledShared = false;
     static constexpr uint32_t DpP = 0, plane_floats = 0;
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
@@ -357,6 +359,8 @@ __device__ __forceinline__ RowBase load_rowbase_at(const_f64_p tile_rows, uint32
     rb.c = tile_rows[4 * i + 0]; rb.s = tile_rows[4 * i + 1]; rb.nf = tile_rows[4 * i + 2]; rb.pad_ = 0.0;
     return rb;
 }
+
+__device__ __forceinline__ uint32_t opaque_u32(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 
 // tile-relative sample index m -> padded LDS element  m + kPad * (m / PD)  (PD = D except for the register-tiled FIR; no pad for odd D)
 template <class GeoT>
@@ -520,6 +524,17 @@ __device__ __forceinline__ void fir_span(const GeoT &geo, const float2 *rowp, ui
                 const uint32_t jj = j0 + blk * 8;
                 if (SNAP && jj >= geo.T / 2 + D && jj < geo.T && ((jj - geo.T / 2) % D) == 0) {   // wave-uniform
                     if (jmax == jj) { snapr = accr; snapi = acci; }
+                }
+                if constexpr ((GeoT::kFlags & kGeoPackedSpan) != 0) {
+                    // both chains of the output as one float pair: v_pk_mul_f32 + v_pk_add_f32 per tap (same two roundings per
+                    // component; half the VALU instructions — the kernel is bound by issue slots, see fir_pair)
+                    typedef float v2f_t __attribute__((ext_vector_type(2)));
+                    v2f_t a2 = {accr, acci};
+                    const float hv[8] = {hh[0].x, hh[0].y, hh[0].z, hh[0].w, hh[1].x, hh[1].y, hh[1].z, hh[1].w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const v2f_t xv = {x[i].x, x[i].y}; const v2f_t hs = {hv[i], hv[i]}; a2 = a2 + xv * hs; }
+                    accr = a2.x; acci = a2.y;
+                    return;
                 }
                 accr = accr + x[0].x * hh[0].x; acci = acci + x[0].y * hh[0].x;
                 accr = accr + x[1].x * hh[0].y; acci = acci + x[1].y * hh[0].y;
@@ -887,17 +902,18 @@ __device__ __forceinline__ float fir_comp_planar(const float *xp, uint32_t jmax,
 // issue slots, not by pipe time: the component-split FIR issues 4 VALU instructions per tap and output, this one 2.  Only
 // G*W lanes take part (half the workgroup at G*W = 128).  Two taps (re, im, re, im) come with each ds_read_b128.
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <class GeoT>
-__device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row of the output */, uint32_t jmax, const float *h) {
+template <class GeoT, bool PACKED = true>
+__device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row of the output */, uint32_t jmax, const float *h, float2 *snap_out = nullptr) {
     constexpr uint32_t D = GeoT::D, Dp = GeoT::Dp, T = GeoT::T, b = GeoT::b0, NB = T / 4;     // blocks of 4 taps = two b128 sample reads
     constexpr int PF = 3;
     static_assert(GeoT::kPad == 2 && T % 4 == 0 && b % 2 == 0 && D % 4 == 0 && NB > (uint32_t)PF, "packed FIR geometry");
     v2f acc = {0.f, 0.f}, snap = {0.f, 0.f};
+    float ar = 0.f, ai = 0.f, sr = 0.f, si = 0.f;          // the scalar form keeps plain floats (a vector type would be re-packed)
     auto cand = [&](uint32_t jj) -> bool { return jj >= T / 2 + D && jj < T && ((jj - T / 2) % D) == 0; };
     auto xoff = [&](uint32_t t) -> uint32_t { return (t / D) * Dp + (t % D); };      // float2 elements
     float4 xa[PF], xb[PF], hh[PF];
     auto load = [&](uint32_t k, int slot) {
-        const uint32_t t0 = b + 4 * k;                      // taps 4k..4k+3; pairs (4k, 4k+1) and (4k+2, 4k+3) never straddle a row (D % 4 == 0, b even... b % 4 may be 2)
+        const uint32_t t0 = b + 4 * k;                      // taps 4k..4k+3: sample pairs (4k, 4k+1) and (4k+2, 4k+3) never straddle a row (D % 4 == 0, b even)
         xa[slot] = *reinterpret_cast<const float4 *>(rowp + xoff(t0));
         xb[slot] = *reinterpret_cast<const float4 *>(rowp + xoff(t0 + 2));
         if constexpr (!GeoT::baked_request) hh[slot] = *reinterpret_cast<const float4 *>(h + 4 * k);
@@ -911,19 +927,28 @@ __device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row o
 #pragma unroll
     for (uint32_t k = 0; k < NB; ++k) {
         const int slot = (int)(k % PF);
-        const v2f xs[4] = {{xa[slot].x, xa[slot].y}, {xa[slot].z, xa[slot].w}, {xb[slot].x, xb[slot].y}, {xb[slot].z, xb[slot].w}};
+        const float xr[4] = {xa[slot].x, xa[slot].z, xb[slot].x, xb[slot].z}, xi[4] = {xa[slot].y, xa[slot].w, xb[slot].y, xb[slot].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t jj = 4 * k + i;
-            if (cand(jj)) { if (jmax == jj) snap = acc; }
             const float hv = tap(jj, slot, i);
-            const v2f hs = {hv, hv};
-            acc = acc + xs[i] * hs;                        // (re, im) * h, then +=: one v_pk_mul_f32, one v_pk_add_f32
+            if constexpr (PACKED) {
+                if (cand(jj)) { if (jmax == jj) snap = acc; }
+                const v2f xs = {xr[i], xi[i]}, hs = {hv, hv};
+                acc = acc + xs * hs;                       // (re, im) * h, then +=: one v_pk_mul_f32, one v_pk_add_f32
+            } else {                                       // two scalar chains (FIR-dominated shapes: shorter dependent latency per tap)
+                if (cand(jj)) { if (jmax == jj) { sr = ar; si = ai; } }
+                ar = ar + xr[i] * hv;
+                ai = ai + xi[i] * hv;
+            }
         }
-        asm volatile("" : "+v"(acc));                       // pin the add chain inside its block (see fir_comp)
+        if constexpr (PACKED) asm volatile("" : "+v"(acc));      // pin the add chain(s) inside their block (see fir_comp)
+        else asm volatile("" : "+v"(ar), "+v"(ai));
         if (k + PF < NB) load(k + PF, slot);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (!PACKED) { acc.x = ar; acc.y = ai; snap.x = sr; snap.y = si; }
+    if (snap_out) { *snap_out = make_float2(snap.x, snap.y); return make_float2(acc.x, acc.y); }      // shared-FIR mode keeps both
     const v2f r = jmax < T ? snap : acc;
     return make_float2(r.x, r.y);
 }
@@ -1301,7 +1326,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                     if (jmax < T) reinterpret_cast<float *>(trc + qi)[part] = snapv;
                 }
             } else
-            for (uint32_t qi = tid; qi < Q; qi += NT) {
+            for (uint32_t qi = opaque_u32(tid); qi < Q; qi += NT) {      // opaque start: per-lane LDS addresses are recomputed per tile, not hoisted and spilled
                 uint32_t jmax = T;
                 if (qi + ntrunc >= W) {                      // may be in the truncated tail of window g
                     const uint32_t g = (qi - (W - ntrunc)) / S, k = qi - g * S;
@@ -1310,7 +1335,11 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 const float2 *rowp = raw + (size_t)(qi + geo.a0) * Dp;
                 float accr = 0.f, acci = 0.f;
                 float2 snap = make_float2(0.f, 0.f);
-                if constexpr (GeoT::kFixed) {
+                if constexpr (GeoT::kUnrolledShared) {
+                    // straight-line, pinned tap loop (taps may be immediates: FLAGS_ bit 1), two scalar chains per lane
+                    const float2 full = fir_pair<GeoT, false>(rowp, jmax, tapl, &snap);
+                    accr = full.x; acci = full.y;
+                } else if constexpr (GeoT::kFixed) {
                     fir_span<false, GeoT, true>(geo, rowp, geo.b0, 0, T, jmax, tapl, accr, acci, &snap);
                 } else {
                     fir_span<false>(geo, rowp, geo.b0, 0, T, T, tapl, accr, acci);
@@ -1324,7 +1353,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 if (jmax < T) trc[qi] = snap;
             }
             __syncthreads();
-            for (uint32_t o = tid; o < n_out; o += NT) {
+            uint32_t o_first = tid;
+            asm volatile("" : "+v"(o_first));
+            for (uint32_t o = o_first; o < n_out; o += NT) {
                 const uint32_t g = o >> logW, k = o & (W - 1);
                 const uint32_t qi = g * S + k;
                 const bool tr = (W - k) * D + T / 2 < T;

@@ -886,7 +886,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 15 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 63 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -907,6 +907,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
         // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
         const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
+        if (flagsv & kGeoUnrolledFir) noslp = 1;       // its scalar accumulate chains must stay scalar
         return JitKey{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, lb, nt,
                       p->W, p->S, p->D, p->T, g, tune[3], tune[2], noslp, padv, batchv, flagsv,
                       (flagsv & kGeoBakedTaps) ? fnv1a(p->taps_h.data(), p->taps_h.size() * sizeof(float)) : 0ull};
@@ -965,9 +966,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         }
         // A built-in packed-FIR kernel re-specialised with the plan's OWN filter baked in (taps as immediates: no LDS reads, no
         // registers for them; +2-3 % on the 16 GiB stream): worth a compile only for streams of several GiB, falls back silently.
-        if (!want && !heavy && !tuned && p->fixed && jit_ok && (p->fixed->flags & kGeoNoSplit) && p->nt == kThreads &&
+        if (!want && !heavy && !tuned && p->fixed && jit_ok && (p->fixed->flags & (kGeoNoSplit | kGeoUnrolledFir)) &&
             (policy == QD_KERNEL_SPECIALISE || in_bytes >= (4ull << 30))) {
             JitKey k = make_key(G, p->nt, p->fixed->lb, 0, pad, batch, kflags | kGeoBakedTaps);
+            // the table's prefetch shape and FIR knobs, not the heuristic ones (e.g. the 4-row chunks of the cf32 FSK kernel)
+            k.rch = p->fixed->rch; k.whole = p->fixed->whole; k.firb = (uint32_t)p->fixed->firb; k.firr = (uint32_t)p->fixed->firr;
+            k.noslp = (p->fixed->flags & kGeoUnrolledFir) ? 1 : 0;
             p->jit_fn = jit_chain_kernel(k, &p->jit_note, true, &p->taps_h);
         }
     }
