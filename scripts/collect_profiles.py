@@ -13,6 +13,9 @@ for f in sorted(os.listdir(src)):
     if not f.startswith(rnd + "_"):
         continue
     name = f[len(rnd) + 1:]
+    if name.startswith("bench_"):                           # bench.py lines of the same box: copied as they are
+        shutil.copy(os.path.join(src, f), os.path.join(dst, name))
+        continue
     shutil.copy(os.path.join(src, f), os.path.join(dst, name.replace(".json", "_summary.json") if f.endswith(".json") else name))
     if f.endswith(".json"):
         d = json.load(open(os.path.join(src, f)))
