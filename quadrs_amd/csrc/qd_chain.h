@@ -138,7 +138,8 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
     return ((tile_raw / D + 1) * ct_planar_pitch(D) + 7) & ~7u;
 }
 
-constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32;   // FixedGeo FLAGS_ bits
+constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32,
+                   kGeoDeferFft = 64;   // FixedGeo FLAGS_ bits
 
 template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1, uint32_t BATCH_ = 1,
           uint32_t FLAGS_ = 0>
@@ -173,6 +174,7 @@ struct FixedGeo {
     static constexpr uint32_t pshift = ct_pow2(PD) ? ct_log2(PD) : 0xffffffffu;
     __device__ __forceinline__ explicit FixedGeo(const ChainParams &) {}
     static constexpr uint32_t W = W_, S = S_, D = D_, T = T_, G = G_;
+    static constexpr uint32_t G_ct = G_, W_ct = W_;
     static constexpr uint32_t logW = ct_log2(W_);
     // LDS pad elements per pad period.  1: odd lane stride, conflict-free single ds_read_b64 — but hipcc merges
     // neighbouring reads into ds_read2_b64, which gfx950 serves at half the bytes per clock.  2 (even D, even
@@ -218,7 +220,7 @@ struct FixedGeo {
 struct DynGeo {
     static constexpr bool kFixed = false;
     static constexpr uint32_t kBatch = 1;
-    static constexpr uint32_t kFlags = 0, G_ct = 1;
+    static constexpr uint32_t kFlags = 0, G_ct = 1, W_ct = 1;
     static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false, kUnrolledShared = false;
     static constexpr uint32_t DpP = 0, plane_floats = 0;
     static constexpr bool kShared = false;
@@ -404,7 +406,7 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
             float2 m[SPL];
             nco_mul_n<NCO == 2, SPL>(rb, lr, P.ratio, m);          // the SPL f64 chains issued interleaved
 #pragma unroll
-            for (int u = 0; u < SPL; ++u) x[u] = cmul(x[u], m[u]);   // buf[i] *= mul (src/shift.rs:51)
+            for (int u = 0; u < SPL; ++u) x[u] = cmul_pk(x[u], m[u]);   // buf[i] *= mul (src/shift.rs:51)
         }
     }
     if constexpr (GeoT::kPlanar && NT == 256) {
@@ -924,6 +926,37 @@ __device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row o
     };
 #pragma unroll
     for (int k = 0; k < PF; ++k) load(k, k);
+    if constexpr (PACKED && !GeoT::baked_request) {
+        // Taps from LDS, four per ds_read_b128, used straight out of the register pair they arrive in: op_sel picks the pair's
+        // low or high word for BOTH halves of the packed multiply, so no tap is ever splat into a register pair of its own
+        // (hipcc emits a v_mov per tap for that, or an s_mov per tap for immediates).  One asm statement per block of four taps:
+        // 4 v_pk_mul_f32 + 4 v_pk_add_f32 in chain order — the statement is also what keeps the adds next to their products.
+        // 11 instructions per four taps (3 LDS reads + 8 VALU) against 18 with the taps as immediates.
+#pragma unroll
+        for (uint32_t k = 0; k < NB; ++k) {
+            const int slot = (int)(k % PF);
+            if (cand(4 * k)) { if (jmax == 4 * k) snap = acc; }                 // candidates are multiples of four (D % 4 == 0, T/2 % 4 == 0)
+            static_assert((T / 2) % 4 == 0, "snapshot taps sit on block boundaries");
+            const v2f x0 = {xa[slot].x, xa[slot].y}, x1 = {xa[slot].z, xa[slot].w}, x2 = {xb[slot].x, xb[slot].y}, x3 = {xb[slot].z, xb[slot].w};
+            const v2f h01 = {hh[slot].x, hh[slot].y}, h23 = {hh[slot].z, hh[slot].w};
+            v2f p0, p1;
+            asm volatile("v_pk_mul_f32 %1, %3, %7 op_sel_hi:[1,0]\n\t"
+                         "v_pk_mul_f32 %2, %4, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %0, %0, %1\n\t"
+                         "v_pk_mul_f32 %1, %5, %8 op_sel_hi:[1,0]\n\t"
+                         "v_pk_add_f32 %0, %0, %2\n\t"
+                         "v_pk_mul_f32 %2, %6, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %0, %0, %1\n\t"
+                         "v_pk_add_f32 %0, %0, %2"
+                         : "+v"(acc), "=&v"(p0), "=&v"(p1)
+                         : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23));
+            if (k + PF < NB) load(k + PF, slot);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (snap_out) { *snap_out = make_float2(snap.x, snap.y); return make_float2(acc.x, acc.y); }
+        const v2f r = jmax < T ? snap : acc;
+        return make_float2(r.x, r.y);
+    }
 #pragma unroll
     for (uint32_t k = 0; k < NB; ++k) {
         const int slot = (int)(k % PF);
@@ -996,6 +1029,13 @@ __device__ __forceinline__ float2 fir_prefix(const float2 *raw, uint32_t t0, uin
     return make_float2(ar, ai);
 }
 
+// deferred FFT (see k_chain)
+template <class GeoT, bool HAS_FIR>
+constexpr bool defer_fft_ok(uint32_t nt) {
+    if constexpr (!GeoT::kFixed) return false;
+    else return HAS_FIR && GeoT::kPairFir && (GeoT::kFlags & kGeoDeferFft) != 0 && GeoT::kBatch == 2 && (GeoT::G * GeoT::W) % 64 == 0 && GeoT::G * GeoT::W * 2 <= nt;
+}
+
 // fast phase 1 (see k_chain): the tile starts on a row boundary whatever its index and is exactly RCH rows long
 template <int FMT, int NT, class GeoT>
 constexpr bool fast_p1_ok(int rch, bool whole, bool aligned) {
@@ -1025,10 +1065,16 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
-    constexpr uint32_t kBatch = GeoT::kBatch;
+    // Deferred FFT (FLAGS_ bit 6, packed FIR with G*W <= NT/2): the FIR keeps G*W/64 waves busy and the FFT + epilogue one wave, so
+    // the FFT + epilogue of tile i-1 run on an otherwise idle wave WHILE the FIR waves work on tile i (two FFT slots, used
+    // alternately).  The FFT is then wave-local — no workgroup barrier between its passes — and a tile costs the workgroup two
+    // barriers and phase 1 + FIR of latency instead of four barriers and phase 1 + FIR + FFT + epilogue.
+    constexpr bool kDefer = defer_fft_ok<GeoT, HAS_FIR>((uint32_t)NT);
+    constexpr uint32_t kSlots = GeoT::kBatch;                 // FFT slots in LDS
+    constexpr uint32_t kBatch = kDefer ? 1u : GeoT::kBatch;   // tiles per FFT batch
     constexpr uint32_t kLutElems = (FMT == 1 || FMT == 2) ? 256u : 0u;
     float2 *fb0 = raw + geo.lds_raw_elems;                    // kBatch slots of G*W decimated samples (FFT buffers)
-    float2 *twl = fb0 + (size_t)kBatch * geo.G * geo.W;       // radix-4 layer twiddles (< W entries), staged once
+    float2 *twl = fb0 + (size_t)kSlots * geo.G * geo.W;       // radix-4 layer twiddles (< W entries), staged once
     float *tapl = reinterpret_cast<float *>(twl + geo.W);     // FIR taps (T floats, padded to a multiple of 4)
     float *lut = tapl + ((GeoT::kBakedTaps && NT == 256) ? 0u : ((geo.T + 3) & ~3u));   // 8-bit unpack table (8-bit formats only); baked taps take no LDS
     // shared-FIR mode (overlapping windows): every decimated output of the tile once + its truncated variant
@@ -1036,7 +1082,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     float2 *trc = dec + ((geo.G - 1) * geo.S + geo.W);
     // batched FFT: where each parked tile's output goes ({window index relative to out, low / high word; window count})
     uint32_t *bmeta = reinterpret_cast<uint32_t *>(GeoT::kShared ? trc + ((geo.G - 1) * geo.S + geo.W) : dec);
-    uint32_t *wq = bmeta + 4 * kBatch;                         // tile queue hand-over: {tile lo, hi} x 2
+    uint32_t *wq = bmeta + 4 * kSlots;                         // tile queue hand-over: {tile lo, hi} x 2
 
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
@@ -1137,6 +1183,96 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     double rt_touch = 0.0;   // keeps the row-table L2 prefetch loads alive (see prefetch_rowtab)
+    // deferred FFT: the previous tile, parked in FFT slot dpar ^ 1
+    uint32_t dpar = 0, dprev_gcnt = 0;
+    uint64_t dprev_w0 = 0;
+    bool dprev_valid = false;
+    // One wave transforms the parked tile and writes its output: LDS operations of one wave execute in order, so the passes
+    // are separated by a compiler-level fence only.
+    auto wave_fft_epilogue = [&](float2 *fbp, uint64_t pw0, uint32_t pg) {
+        uint32_t lane = tid & 63u;
+        asm volatile("" : "+v"(lane));            // opaque: per-lane LDS / output addresses are rebuilt per tile, not hoisted out of the tile loop and spilled
+        auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+        const uint32_t base = geo.base_len, log_tpw = geo.logW - geo.log_base;
+        const uint32_t n_task = pg << log_tpw;
+        for (uint32_t t = lane; t < n_task; t += 64) {
+            float2 *d = fbp + (size_t)t * base;
+            if (base == 16) {
+                float2 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = d[i];
+                bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d[i] = v[i];
+            } else if (base == 8) {
+                float2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = d[i];
+                bf8(v, P.root2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] = v[i];
+            } else if (base == 4) {
+                float2 v0 = d[0], v1 = d[1], v2 = d[2], v3 = d[3];
+                bf4(v0, v1, v2, v3);
+                d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+            } else if (base == 2) {
+                float2 v0 = d[0], v1 = d[1];
+                bf2(v0, v1);
+                d[0] = v0; d[1] = v1;
+            }
+        }
+        uint32_t cols = base, log_cols = geo.log_base;
+        const float2 *tw = twl;
+        for (uint32_t layer = 0; layer < geo.layers; ++layer) {
+            wsync();
+            const uint32_t n_bf = (pg << geo.logW) >> 2;
+            for (uint32_t t = lane; t < n_bf; t += 64) {
+                const uint32_t chunk = t >> log_cols, i = t & (cols - 1);
+                float2 *d = fbp + (size_t)chunk * 4 * cols + i;
+                float2 s0 = d[0];
+                float2 s1 = cmul(d[cols], tw[3 * i]);
+                float2 s2 = cmul(d[2 * cols], tw[3 * i + 1]);
+                float2 s3 = cmul(d[3 * cols], tw[3 * i + 2]);
+                bf4(s0, s1, s2, s3);
+                d[0] = s0; d[cols] = s1; d[2 * cols] = s2; d[3 * cols] = s3;
+            }
+            tw += 3 * cols;
+            cols *= 4;
+            log_cols += 2;
+        }
+        wsync();
+        const uint64_t wrel = pw0 - P.out_window0;
+        const uint32_t n_out_s = pg << geo.logW;
+        if (P.epi == 2) {
+            // freq_levels: the norms replace the transformed samples in place (every lane reads its share first), then one lane
+            // per window forms the two sequential half sums (src/fft.rs:95-97)
+            constexpr uint32_t K = GeoT::kFixed ? (GeoT::G_ct * GeoT::W_ct + 63) / 64 : 1;
+            float nm[K];
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; nm[k] = o < n_out_s ? norm_ref(fbp[o]) : 0.f; }
+            wsync();
+            float *nb = reinterpret_cast<float *>(fbp);
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; if (o < n_out_s) nb[o] = nm[k]; }
+            wsync();
+            if (lane < pg) {
+                const float *q = nb + (lane << geo.logW);
+                float first = 0.f, second = 0.f;
+                for (uint32_t k = 0; k < geo.W / 2; ++k) first = first + q[k];
+                for (uint32_t k = geo.W / 2; k < geo.W; ++k) second = second + q[k];
+                reinterpret_cast<uint8_t *>(P.out)[wrel + lane] = first < second ? 0 : 1;
+            }
+        } else {
+            float *outf = reinterpret_cast<float *>(P.out) + (wrel << geo.logW);
+            uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << geo.logW);
+            for (uint32_t o = lane; o < n_out_s; o += 64) {
+                const float2 xv = fbp[o ^ (geo.W >> 1)];
+                const float nm = norm_ref(xv);
+                if (P.epi == 0) outf[o] = nm;
+                else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
+            }
+        }
+    };
     uint32_t bslot = 0;      // parked tiles of the current FFT batch (wave-uniform)
     QD_STAMP_DECL
     QD_STAMP_START();
@@ -1274,6 +1410,41 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         QD_STAMP_AT(1);
 
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (kDefer) {
+            constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct;
+            float2 *fb_cur = fb0 + (size_t)dpar * GW, *fb_prev = fb0 + (size_t)(dpar ^ 1u) * GW;
+            const uint32_t n_out_d = g_cnt << logW;
+            const uint32_t log_width_d = 2 * geo.layers;
+            if (tid < GW) {                                    // the FIR waves: one lane per complex output
+                if (tid < n_out_d) {
+                    const uint32_t g = tid >> logW, k = tid & (W - 1);
+                    uint32_t jmax = (W - k) * D + T / 2;
+                    if (jmax > T) jmax = T;
+                    const float2 *rp = raw + (size_t)(g * S + k + geo.a0) * Dp;
+                    const float2 v = QD_DBG(P, 2) ? rp[0] : fir_pair<GeoT>(rp, jmax, tapl);      // dbg: timing-only ablation
+                    const uint32_t xx = k & ((1u << log_width_d) - 1), yy = k >> log_width_d;
+                    fb_cur[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
+                }
+            } else if ((tid >> 6) == GW / 64 && dprev_valid) { // the first spare wave: previous tile's FFT + epilogue
+                wave_fft_epilogue(fb_prev, dprev_w0, dprev_gcnt);
+            }
+            QD_STAMP_AT(2);
+            if (dyn && tid == 0) {
+                const uint64_t t2 = claim_resolve(claim);
+                wq[0] = (uint32_t)t2; wq[1] = (uint32_t)(t2 >> 32);
+            }
+            const TileGeo tg_nx = tile_geo<FMT, NT>(P, geo, tile_n, n_tiles);
+            __syncthreads();                                   // fb_cur complete, fb_prev consumed, the raw tile free
+            QD_STAMP_AT(3);
+            dprev_w0 = w0; dprev_gcnt = g_cnt; dprev_valid = true; dpar ^= 1u;
+            tile = tile_n;
+            if (dyn) tile_n = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
+            else { walk_local += walk_step; tile_n = walk_tile(walk_local + walk_step); }
+            rt_touch += rt_pf;
+            tg = tg_nx;
+            QD_STAMP_TILE();
+            continue;
+        }
         // ---------------- phase 2: FIR + decimate (or plain window gather), scatter for the FFT
         float2 *fb = fb0 + (size_t)bslot * geo.G * geo.W;     // this tile's slot of the FFT batch
         const uint32_t n_out = g_cnt << logW;
@@ -1443,7 +1614,8 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 const uint32_t g = o >> logW, k = o & (W - 1);
                 uint32_t jmax = (W - k) * D + T / 2;
                 if (jmax > T) jmax = T;
-                const float2 v = fir_pair<GeoT>(raw + (size_t)(g * S + k + geo.a0) * Dp, jmax, tapl);
+                const float2 *rp = raw + (size_t)(g * S + k + geo.a0) * Dp;
+                const float2 v = QD_DBG(P, 2) ? rp[0] : fir_pair<GeoT>(rp, jmax, tapl);      // dbg: timing-only ablation
                 const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
                 fb[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
             }
@@ -1626,6 +1798,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         QD_STAMP_AT(7);
         QD_STAMP_TILE();
         tg = tg_next;
+    }
+    if constexpr (kDefer) {
+        if (dprev_valid && (tid >> 6) == (GeoT::G_ct * GeoT::W_ct) / 64) wave_fft_epilogue(fb0 + (size_t)(dpar ^ 1u) * (GeoT::G_ct * GeoT::W_ct), dprev_w0, dprev_gcnt);
     }
     if (dyn && tid == 0) {       // the last workgroup to leave re-arms the queue for the next launch
         if (atomicAdd(&P.work[16 * 8], 1ull) == (unsigned long long)gridDim.x - 1) {

@@ -312,8 +312,9 @@ const FixedEntry kFixed[] = {
     // north_star target sentence: 200-tap FIR decimate 32 -> 128-pt FFT
     // packed lane-per-output FIR on a 16-byte-row tile (FixedGeo FLAGS_ bit 2, PAD 2): half the VALU instructions of the FIR
     // + row-aligned fast phase 1 (bit 3): buffer loads with a per-tile descriptor, compile-time row offsets
-    QD_FIXED_F(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 12, "cfg3p"),
-    QD_FIXED_F(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 12, "cfg3p"),
+    // + deferred FFT (bit 6, two FFT slots): the previous tile's FFT + epilogue on a wave the FIR leaves idle
+    QD_FIXED_FB(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 76, "cfg3p"),
+    QD_FIXED_FB(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 76, "cfg3p"),
     // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
@@ -886,7 +887,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 63 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 127 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -964,9 +965,11 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad, batch, kflags), &p->jit_note, may_compile, &p->taps_h);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "tile_hint build failed: %s", p->jit_note.c_str());
         }
-        // A built-in packed-FIR kernel re-specialised with the plan's OWN filter baked in (taps as immediates: no LDS reads, no
-        // registers for them; +2-3 % on the 16 GiB stream): worth a compile only for streams of several GiB, falls back silently.
-        if (!want && !heavy && !tuned && p->fixed && jit_ok && (p->fixed->flags & (kGeoNoSplit | kGeoUnrolledFir)) &&
+        // A built-in straight-line FIR kernel (scalar chains of overlapping-window shapes) re-specialised with the plan's OWN filter
+        // baked in (taps as immediates: no LDS reads, no registers for them; cfg3 27.8 -> 24.6 ms): worth a compile only for
+        // streams of several GiB, falls back silently.  The packed lane-per-output FIR does not need it: it multiplies by the
+        // taps straight out of the register pairs an LDS read delivers (fir_pair), which measures the same as immediates.
+        if (!want && !heavy && !tuned && p->fixed && jit_ok && (p->fixed->flags & kGeoUnrolledFir) &&
             (policy == QD_KERNEL_SPECIALISE || in_bytes >= (4ull << 30))) {
             JitKey k = make_key(G, p->nt, p->fixed->lb, 0, pad, batch, kflags | kGeoBakedTaps);
             // the table's prefetch shape and FIR knobs, not the heuristic ones (e.g. the 4-row chunks of the cf32 FSK kernel)
