@@ -139,7 +139,8 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
 }
 
 constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32,
-                   kGeoDeferFft = 64;   // FixedGeo FLAGS_ bits
+                   kGeoDeferFft = 64, kGeoPackedTile = 128;   // FixedGeo FLAGS_ bits
+typedef float v2f __attribute__((ext_vector_type(2)));      // operand type of the v_pk_*_f32 instructions
 
 template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1, uint32_t BATCH_ = 1,
           uint32_t FLAGS_ = 0>
@@ -212,6 +213,8 @@ struct FixedGeo {
                                      D_ % 4 == 0 && T_ >= 32;
     static constexpr bool kUnrolledShared = (FLAGS_ & kGeoUnrolledFir) && kShared && kFirTile == 1 && kPad == 2 && T_ % 4 == 0 &&
                                             ((T_ - T_ / 2) % D_) % 2 == 0 && D_ % 4 == 0 && T_ >= 32;
+    // register-tiled FIR as straight-line packed code with in-chain snapshots (fir_tiled2_pk): FLAGS_ bit 7, two outputs per lane
+    static constexpr bool kPackedTile = (FLAGS_ & kGeoPackedTile) && !kShared && kFirTile == 2 && kPad == 2 && (T_ / 2) % 4 == 0 && D_ / 4 <= 8;
     static constexpr bool kPlanar = planar_geometry && split_ok(256u);
     static constexpr bool kBakedTaps = baked_request && kPlanar;       // only the planar FIR takes its taps as immediates
     static constexpr uint32_t lds_raw_elems = kPlanar ? plane_floats : lds_raw_elems_std;      // float2 elements
@@ -221,7 +224,7 @@ struct DynGeo {
     static constexpr bool kFixed = false;
     static constexpr uint32_t kBatch = 1;
     static constexpr uint32_t kFlags = 0, G_ct = 1, W_ct = 1;
-    static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false, kUnrolledShared = false;
+    static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false, kUnrolledShared = false, kPackedTile = false;
     static constexpr uint32_t DpP = 0, plane_floats = 0;
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
@@ -903,7 +906,6 @@ __device__ __forceinline__ float fir_comp_planar(const float *xp, uint32_t jmax,
 // instructions.  On gfx950 a packed op occupies the pipe as long as two scalar ones, but the chain kernel is bound by
 // issue slots, not by pipe time: the component-split FIR issues 4 VALU instructions per tap and output, this one 2.  Only
 // G*W lanes take part (half the workgroup at G*W = 128).  Two taps (re, im, re, im) come with each ds_read_b128.
-typedef float v2f __attribute__((ext_vector_type(2)));
 template <class GeoT, bool PACKED = true>
 __device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row of the output */, uint32_t jmax, const float *h, float2 *snap_out = nullptr) {
     constexpr uint32_t D = GeoT::D, Dp = GeoT::Dp, T = GeoT::T, b = GeoT::b0, NB = T / 4;     // blocks of 4 taps = two b128 sample reads
@@ -986,6 +988,164 @@ __device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row o
     return make_float2(r.x, r.y);
 }
 
+// Register-tiled FIR, two outputs per lane, as straight-line packed code (helper-mode kernels: no truncated outputs on the main
+// lanes).  Same walk as fir_tiled<2>: the lane reads the D + T samples its two outputs touch once, sample i feeds output 0 with
+// tap i and output 1 with tap i - D, every chain in ascending-tap order with separately rounded multiply and add.  What
+// changes is the instruction stream: fir_tiled's rolled loop spends 75 instructions per 8 taps (32 packed VALU, 8 register
+// copies to splat taps, ~20 scalar address operations, LDS reads through freshly materialised address registers) and a wave
+// issues one instruction per ~5 cycles — with two FIR waves per SIMD the phase is bound by instruction issue, not by the
+// VALU.  Here every LDS offset is an immediate, a tap is used straight out of the register pair it arrives in (op_sel picks
+// the word for both halves of the packed multiply), and the tap blocks are shared between the two outputs (output 1 uses the
+// block output 0 used D/4 blocks earlier): 20 instructions per 4 samples (16 VALU, 3 LDS reads, 1 wait).
+template <class GeoT>
+__device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *h, float2 *full, const uint32_t *jm, float2 *snap) {
+    constexpr uint32_t D = GeoT::D, T = GeoT::T, c = GeoT::c;
+    constexpr uint32_t L = D + T, NB = L / 4, HB = T / 4, LAG = D / 4;      // sample blocks, tap blocks, output 1's lag in blocks
+    constexpr int PF = 3, NS = PF + (int)LAG + 1;                            // sample / tap blocks in flight, live tap slots
+    static_assert(GeoT::kFirTile == 2 && GeoT::PD == 2 * D && GeoT::pshift != 0xffffffffu && GeoT::kPad == 2, "two-output packed FIR: layout");
+    static_assert(D % 4 == 0 && T % 4 == 0 && c % 4 == 0 && (T / 2) % 4 == 0 && NB > (uint32_t)PF && LAG >= 1 && LAG <= 8, "two-output packed FIR: geometry");
+    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+    // Truncated outputs (the last kNtrunc of a window) are prefixes of their own full chain: the accumulator is
+    // copied when the chain reaches the lane's jmax.  Only the wave that owns such outputs takes the (wave-uniform) branches.
+    const bool need_snap = __builtin_amdgcn_ballot_w64(jm[0] < T || jm[1] < T) != 0;
+    auto cand = [&](uint32_t j) -> bool { return j >= T / 2 + D && j < T && ((j - T / 2) % D) == 0; };
+    float4 xa[PF], xb[PF], hh[NS];
+    // LDS address of the taps, kept in ONE vector register: every tap read is base + immediate (left uniform, hipcc forms one
+    // scalar address per block — 128 scalars, spilled to vector lanes — and moves each into a vector register for its read)
+    typedef float f4n __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const f4n lds_f4;
+    uint32_t hbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)h;
+    asm volatile("" : "+v"(hbase));
+    const lds_f4 *hl = (const lds_f4 *)(uintptr_t)hbase;
+    auto load = [&](uint32_t b) {
+#if defined(QD_FIR_ABL) && (QD_FIR_ABL & 2)
+        if (b >= (uint32_t)PF) return;                                       // timing-only ablation (development builds): no LDS reads past the first blocks
+#endif
+        const uint32_t t = c + 4 * b;                                        // a block of four never straddles a pad (pad period 2D, a multiple of 4)
+        const float2 *pp = lanep + (t + GeoT::kPad * (t >> GeoT::pshift));
+        xa[b % PF] = *reinterpret_cast<const float4 *>(pp);
+        xb[b % PF] = *reinterpret_cast<const float4 *>(pp + 2);
+        if (b < HB) { const f4n q = hl[b]; hh[b % NS] = make_float4(q.x, q.y, q.z, q.w); }
+    };
+#pragma unroll
+    for (int b = 0; b < PF; ++b) load(b);
+#pragma clang loop unroll(full)
+    for (uint32_t b = 0; b < NB; ++b) {
+        const float4 A = xa[b % PF], B = xb[b % PF];
+        const v2f x0 = {A.x, A.y}, x1 = {A.z, A.w}, x2 = {B.x, B.y}, x3 = {B.z, B.w};
+        v2f t0, t1, t2, t3;
+        if ((b < HB && cand(4 * b)) || (b >= LAG && cand(4 * (b - LAG)))) {  // compile-time: a snapshot tap starts at this block
+            if (need_snap) {
+                if (b < HB && cand(4 * b)) { if (jm[0] == 4 * b) s0 = a0; }
+                if (b >= LAG && cand(4 * (b - LAG))) { if (jm[1] == 4 * (b - LAG)) s1 = a1; }
+            }
+        }
+#if defined(QD_FIR_ABL) && (QD_FIR_ABL & 1)
+        {                                                                    // timing-only ablation (development builds): LDS reads without the arithmetic
+            asm volatile("" :: "v"(x0), "v"(x3), "v"(hh[b % NS].x));
+            if (b + PF < NB) load(b + PF);
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
+#endif
+        if (b >= LAG && b < HB) {                                            // both outputs take this block
+            const float4 H = hh[b % NS], G = hh[(b - LAG) % NS];
+            const v2f h01 = {H.x, H.y}, h23 = {H.z, H.w}, g01 = {G.x, G.y}, g23 = {G.z, G.w};
+            asm volatile("v_pk_mul_f32 %2, %6, %10 op_sel_hi:[1,0]\n\t"
+                         "v_pk_mul_f32 %3, %6, %12 op_sel_hi:[1,0]\n\t"
+                         "v_pk_mul_f32 %4, %7, %10 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %0, %0, %2\n\t"
+                         "v_pk_mul_f32 %5, %7, %12 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %1, %1, %3\n\t"
+                         "v_pk_mul_f32 %2, %8, %11 op_sel_hi:[1,0]\n\t"
+                         "v_pk_add_f32 %0, %0, %4\n\t"
+                         "v_pk_mul_f32 %3, %8, %13 op_sel_hi:[1,0]\n\t"
+                         "v_pk_add_f32 %1, %1, %5\n\t"
+                         "v_pk_mul_f32 %4, %9, %11 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %0, %0, %2\n\t"
+                         "v_pk_mul_f32 %5, %9, %13 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %1, %1, %3\n\t"
+                         "v_pk_add_f32 %0, %0, %4\n\t"
+                         "v_pk_add_f32 %1, %1, %5"
+                         : "+v"(a0), "+v"(a1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                         : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23), "v"(g01), "v"(g23));
+        } else {                                                             // the first LAG blocks: output 0 only; the last LAG: output 1 only
+            const float4 H = hh[(b < HB ? b : b - LAG) % NS];
+            const v2f h01 = {H.x, H.y}, h23 = {H.z, H.w};
+            v2f &acc = b < HB ? a0 : a1;
+            asm volatile("v_pk_mul_f32 %1, %3, %7 op_sel_hi:[1,0]\n\t"
+                         "v_pk_mul_f32 %2, %4, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %0, %0, %1\n\t"
+                         "v_pk_mul_f32 %1, %5, %8 op_sel_hi:[1,0]\n\t"
+                         "v_pk_add_f32 %0, %0, %2\n\t"
+                         "v_pk_mul_f32 %2, %6, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                         "v_pk_add_f32 %0, %0, %1\n\t"
+                         "v_pk_add_f32 %0, %0, %2"
+                         : "+v"(acc), "=&v"(t0), "=&v"(t1)
+                         : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23));
+        }
+        if (b + PF < NB) load(b + PF);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    full[0] = make_float2(a0.x, a0.y);
+    full[1] = make_float2(a1.x, a1.y);
+    snap[0] = make_float2(s0.x, s0.y);
+    snap[1] = make_float2(s1.x, s1.y);
+}
+
+// Truncated tail outputs, packed: see fir_prefix.  Eight taps per trip (four sample reads, two tap reads, one asm statement of
+// 16 packed instructions), the next trip's reads in flight; a lane drops out at its own jmax (a multiple of 8).
+template <class GeoT>
+__device__ __forceinline__ float2 fir_prefix_pk(const float2 *raw, uint32_t t0, uint32_t jmax, const float *h) {
+    constexpr uint32_t T = GeoT::T;
+    static_assert(GeoT::kPad == 2 && GeoT::pshift != 0xffffffffu && (GeoT::PD % 8) == 0, "packed prefix: 16-byte rows, blocks of 8 inside a pad period");
+    v2f acc = {0.f, 0.f};
+    uint32_t jhi = jmax;                                   // longest prefix in the wave bounds the loop
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)jhi, off); jhi = o > jhi ? o : jhi; }
+    float4 xa[4], xb[4], ha[2], hb[2];
+    auto load = [&](uint32_t jb, float4 *x, float4 *hh) {   // reads past a lane's own jmax stay inside its T-sample span
+        const uint32_t t = t0 + jb;
+        // t is a multiple of 8 and the pad term a multiple of 2 elements: 16-byte aligned (said out loud, or hipcc splits the reads)
+        const float4 *pp = static_cast<const float4 *>(__builtin_assume_aligned(raw + (t + GeoT::kPad * (t >> GeoT::pshift)), 16));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = pp[i];
+        const float4 *hp = static_cast<const float4 *>(__builtin_assume_aligned(h + jb, 16));
+        hh[0] = hp[0]; hh[1] = hp[1];
+    };
+    auto mac = [&](uint32_t jb, const float4 *x, const float4 *hh) {
+        if (jb < jmax) {                                   // whole block in or out (jmax is a multiple of 8)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const v2f x0 = {x[2 * q].x, x[2 * q].y}, x1 = {x[2 * q].z, x[2 * q].w}, x2 = {x[2 * q + 1].x, x[2 * q + 1].y}, x3 = {x[2 * q + 1].z, x[2 * q + 1].w};
+                const v2f h01 = {hh[q].x, hh[q].y}, h23 = {hh[q].z, hh[q].w};
+                v2f p0, p1;
+                asm volatile("v_pk_mul_f32 %1, %3, %7 op_sel_hi:[1,0]\n\t"
+                             "v_pk_mul_f32 %2, %4, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                             "v_pk_add_f32 %0, %0, %1\n\t"
+                             "v_pk_mul_f32 %1, %5, %8 op_sel_hi:[1,0]\n\t"
+                             "v_pk_add_f32 %0, %0, %2\n\t"
+                             "v_pk_mul_f32 %2, %6, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                             "v_pk_add_f32 %0, %0, %1\n\t"
+                             "v_pk_add_f32 %0, %0, %2"
+                             : "+v"(acc), "=&v"(p0), "=&v"(p1)
+                             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23));
+            }
+        }
+    };
+    load(0, xa, ha);
+#pragma unroll 1
+    for (uint32_t jb = 0; jb < jhi; jb += 16) {            // two 8-tap blocks per trip, the next one always in flight
+        if (jb + 8 < T) load(jb + 8, xb, hb);
+        mac(jb, xa, ha);
+        __builtin_amdgcn_sched_barrier(0);
+        if (jb + 16 < T) load(jb + 16, xa, ha);
+        mac(jb + 8, xb, hb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return make_float2(acc.x, acc.y);
+}
+
 // Truncated tail outputs on spare lanes (register-tiled kernels whose workgroup has idle waves in the FIR phase):
 // the reference's per-read_at truncation makes the last kNtrunc outputs of a window PREFIXES of the full chain
 // (jmax = T/2 + m*D taps).  Computing them as accumulator snapshots inside the main loop makes the one wave that
@@ -1033,7 +1193,10 @@ __device__ __forceinline__ float2 fir_prefix(const float2 *raw, uint32_t t0, uin
 template <class GeoT, bool HAS_FIR>
 constexpr bool defer_fft_ok(uint32_t nt) {
     if constexpr (!GeoT::kFixed) return false;
-    else return HAS_FIR && GeoT::kPairFir && (GeoT::kFlags & kGeoDeferFft) != 0 && GeoT::kBatch == 2 && (GeoT::G * GeoT::W) % 64 == 0 && GeoT::G * GeoT::W * 2 <= nt;
+    else {
+        constexpr uint32_t GW = GeoT::G * GeoT::W, FL = GeoT::kPackedTile ? GW / 2 : GW;       // lanes the FIR occupies
+        return HAS_FIR && (GeoT::kPairFir || GeoT::kPackedTile) && (GeoT::kFlags & kGeoDeferFft) != 0 && GeoT::kBatch == 2 && FL % 64 == 0 && FL + 64 <= nt;
+    }
 }
 
 // fast phase 1 (see k_chain): the tile starts on a row boundary whatever its index and is exactly RCH rows long
@@ -1065,7 +1228,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
-    // Deferred FFT (FLAGS_ bit 6, packed FIR with G*W <= NT/2): the FIR keeps G*W/64 waves busy and the FFT + epilogue one wave, so
+    // Deferred FFT (FLAGS_ bit 6; packed FIRs that leave at least one wave idle): the FIR keeps G*W/64 (or G*W/128) waves busy and the FFT + epilogue one wave, so
     // the FFT + epilogue of tile i-1 run on an otherwise idle wave WHILE the FIR waves work on tile i (two FFT slots, used
     // alternately).  The FFT is then wave-local — no workgroup barrier between its passes — and a tile costs the workgroup two
     // barriers and phase 1 + FIR of latency instead of four barriers and phase 1 + FIR + FFT + epilogue.
@@ -1411,12 +1574,29 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
         __builtin_amdgcn_s_setprio(1);
         if constexpr (kDefer) {
-            constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct;
+            constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct, FL = GeoT::kPackedTile ? GW / 2 : GW;
             float2 *fb_cur = fb0 + (size_t)dpar * GW, *fb_prev = fb0 + (size_t)(dpar ^ 1u) * GW;
             const uint32_t n_out_d = g_cnt << logW;
             const uint32_t log_width_d = 2 * geo.layers;
-            if (tid < GW) {                                    // the FIR waves: one lane per complex output
-                if (tid < n_out_d) {
+            if (tid < FL) {                                    // the FIR waves
+                if constexpr (GeoT::kPackedTile) {             // two outputs per lane, truncated ones as in-chain snapshots
+                    const uint32_t o0 = tid * 2;
+                    if (o0 < n_out_d) {
+                        const uint32_t g = o0 >> logW, k0 = o0 & (W - 1);
+                        uint32_t jm[2];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) { const uint32_t j2 = (W - (k0 + r)) * D + T / 2; jm[r] = j2 < T ? j2 : T; }
+                        float2 full[2], snp[2];
+                        const uint32_t q0 = g * S + k0;
+                        fir_tiled2_pk<GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / 2)), tapl, full, jm, snp);
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const uint32_t k = k0 + r;
+                            const uint32_t xx = k & ((1u << log_width_d) - 1), yy = k >> log_width_d;
+                            fb_cur[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = jm[r] < T ? snp[r] : full[r];
+                        }
+                    }
+                } else if (tid < n_out_d) {                    // one lane per complex output
                     const uint32_t g = tid >> logW, k = tid & (W - 1);
                     uint32_t jmax = (W - k) * D + T / 2;
                     if (jmax > T) jmax = T;
@@ -1425,7 +1605,8 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                     const uint32_t xx = k & ((1u << log_width_d) - 1), yy = k >> log_width_d;
                     fb_cur[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
                 }
-            } else if ((tid >> 6) == GW / 64 && dprev_valid) { // the first spare wave: previous tile's FFT + epilogue
+            } else if ((tid >> 6) == FL / 64 && dprev_valid) { // the first spare wave: previous tile's FFT + epilogue
+                __builtin_amdgcn_s_setprio(3);                 // one wave's serial work next to FIR waves on its SIMD: it goes first
                 wave_fft_epilogue(fb_prev, dprev_w0, dprev_gcnt);
             }
             QD_STAMP_AT(2);
@@ -1508,7 +1689,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 float2 snap = make_float2(0.f, 0.f);
                 if constexpr (GeoT::kUnrolledShared) {
                     // straight-line, pinned tap loop (taps may be immediates: FLAGS_ bit 1), two scalar chains per lane
-                    const float2 full = fir_pair<GeoT, false>(rowp, jmax, tapl, &snap);
+                    const float2 full = fir_pair<GeoT, !GeoT::baked_request>(rowp, jmax, tapl, &snap);
                     accr = full.x; acci = full.y;
                 } else if constexpr (GeoT::kFixed) {
                     fir_span<false, GeoT, true>(geo, rowp, geo.b0, 0, T, jmax, tapl, accr, acci, &snap);
@@ -1559,7 +1740,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 reinterpret_cast<float *>(fb + (g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base))[part] = v;
             }
         } else
-        if constexpr (GeoT::kFixed && !GeoT::kShared && GeoT::kFirTile > 1 && HAS_FIR && GeoT::helper_ok((uint32_t)NT)) {
+        if constexpr (GeoT::kFixed && !GeoT::kShared && GeoT::kFirTile > 1 && HAS_FIR && GeoT::helper_ok((uint32_t)NT) && !GeoT::kPackedTile) {
             // main lanes: R outputs each, no truncation logic; spare waves: the truncated tails as direct prefixes
             constexpr int R = (int)GeoT::kFirTile;
             constexpr uint32_t NTR = GeoT::kNtrunc, n_main_max = GeoT::G * GeoT::W / R;
@@ -1584,6 +1765,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             } else {
                 const uint32_t hidx = tid - n_main_max;
                 if (NTR > 0 && hidx < g_cnt * NTR) {
+                    // The helper wave's serial prefixes are as long as a main wave's whole share and it sits on a SIMD with two
+                    // main waves: at equal priority it gets a third of the issue slots and the whole workgroup waits for it.
+                    __builtin_amdgcn_s_setprio(3);
                     const uint32_t g = hidx / NTR, k = W - NTR + hidx % NTR;
                     const uint32_t jmax = (W - k) * D + T / 2;           // < T for these k
                     const float2 v = fir_prefix<GeoT>(raw, (g * S + k) * D + GeoT::c, jmax, tapl);
@@ -1600,7 +1784,11 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) { const uint32_t j2 = (W - (k0 + r)) * D + T / 2; jm[r] = j2 < T ? j2 : T; }
                 float2 full[R], snp[R];
-                { const uint32_t q0 = g * S + k0; fir_tiled<R, GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), jm, tapl, full, snp); }
+                {
+                    const uint32_t q0 = g * S + k0;
+                    if constexpr (GeoT::kPackedTile) fir_tiled2_pk<GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), tapl, full, jm, snp);
+                    else fir_tiled<R, GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), jm, tapl, full, snp);
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t k = k0 + r;
@@ -1800,7 +1988,8 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         tg = tg_next;
     }
     if constexpr (kDefer) {
-        if (dprev_valid && (tid >> 6) == (GeoT::G_ct * GeoT::W_ct) / 64) wave_fft_epilogue(fb0 + (size_t)(dpar ^ 1u) * (GeoT::G_ct * GeoT::W_ct), dprev_w0, dprev_gcnt);
+        constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct, FL = GeoT::kPackedTile ? GW / 2 : GW;
+        if (dprev_valid && (tid >> 6) == FL / 64) wave_fft_epilogue(fb0 + (size_t)(dpar ^ 1u) * GW, dprev_w0, dprev_gcnt);
     }
     if (dyn && tid == 0) {       // the last workgroup to leave re-arms the queue for the next launch
         if (atomicAdd(&P.work[16 * 8], 1ull) == (unsigned long long)gridDim.x - 1) {

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Development: board power / clocks while the chain kernel runs (rocm-smi sampled once a second against a long bench run).
 mkdir -p gpurun_out
-wl=${1:-cfg3p}; shift
-timeout -k 10 150 python bench.py --workload $wl --steps 4000 --warmup 5 --no-cpu-baseline --no-others "$@" > gpurun_out/power_bench_$wl.json 2> gpurun_out/power_bench_$wl.err &
+wl=${1:-cfg3p}; steps=${2:-4000}; shift; shift
+timeout -k 10 150 python bench.py --workload $wl --steps $steps --warmup 5 --no-cpu-baseline --no-others "$@" > gpurun_out/power_bench_$wl.json 2> gpurun_out/power_bench_$wl.err &
 pid=$!
 t0=$(date +%s)
 while kill -0 $pid 2>/dev/null; do
