@@ -393,11 +393,19 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
     if constexpr (FMT == 0) {
         x[0] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
         x[1] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
-    } else if constexpr (FMT == 1 || FMT == 2) {
-        x[0] = make_float2(lut[v.x & 0xff], lut[(v.x >> 8) & 0xff]);
-        x[1] = make_float2(lut[(v.x >> 16) & 0xff], lut[v.x >> 24]);
-        x[2] = make_float2(lut[v.y & 0xff], lut[(v.y >> 8) & 0xff]);
-        x[3] = make_float2(lut[(v.y >> 16) & 0xff], lut[v.y >> 24]);
+    } else if constexpr (FMT == 1) {
+        // arithmetic unpack: a 256-entry table in LDS costs one gathered read per component, and 64 lanes hitting a 1 KiB table
+        // collide 4-5 deep in its banks — phase 1 of the cs8 chain was bound by exactly that
+        const uint32_t a = v.x ^ 0x80808080u, b = v.y ^ 0x80808080u;
+        x[0] = make_float2(unpack_cs8_at(a, 0), unpack_cs8_at(a, 1));
+        x[1] = make_float2(unpack_cs8_at(a, 2), unpack_cs8_at(a, 3));
+        x[2] = make_float2(unpack_cs8_at(b, 0), unpack_cs8_at(b, 1));
+        x[3] = make_float2(unpack_cs8_at(b, 2), unpack_cs8_at(b, 3));
+    } else if constexpr (FMT == 2) {
+        x[0] = make_float2(unpack_cu8_at(v.x, 0), unpack_cu8_at(v.x, 1));
+        x[1] = make_float2(unpack_cu8_at(v.x, 2), unpack_cu8_at(v.x, 3));
+        x[2] = make_float2(unpack_cu8_at(v.y, 0), unpack_cu8_at(v.y, 1));
+        x[3] = make_float2(unpack_cu8_at(v.y, 2), unpack_cu8_at(v.y, 3));
     } else {
         x[0] = make_float2(unpack_cs16(v.x & 0xffffu), unpack_cs16(v.x >> 16));
         x[1] = make_float2(unpack_cs16(v.y & 0xffffu), unpack_cs16(v.y >> 16));
@@ -911,6 +919,10 @@ __device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row o
     constexpr uint32_t D = GeoT::D, Dp = GeoT::Dp, T = GeoT::T, b = GeoT::b0, NB = T / 4;     // blocks of 4 taps = two b128 sample reads
     constexpr int PF = 3;
     static_assert(GeoT::kPad == 2 && T % 4 == 0 && b % 2 == 0 && D % 4 == 0 && NB > (uint32_t)PF, "packed FIR geometry");
+#if defined(QD_FIR_ABL) && (QD_FIR_ABL & 4)
+    if (snap_out) *snap_out = rowp[1];                     // timing-only ablation (development builds): no FIR at all
+    return rowp[0];
+#endif
     v2f acc = {0.f, 0.f}, snap = {0.f, 0.f};
     float ar = 0.f, ai = 0.f, sr = 0.f, si = 0.f;          // the scalar form keeps plain floats (a vector type would be re-packed)
     auto cand = [&](uint32_t jj) -> bool { return jj >= T / 2 + D && jj < T && ((jj - T / 2) % D) == 0; };
@@ -1250,8 +1262,6 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t W = geo.W, logW = geo.logW, S = geo.S, D = geo.D, T = geo.T, Dp = geo.Dp;
 
-    if constexpr (FMT == 1) { if (tid < 256) lut[tid] = unpack_cs8(tid); }
-    if constexpr (FMT == 2) { if (tid < 256) lut[tid] = unpack_cu8(tid); }
 
     // Per-lane NCO constants: 3 doubles per sample slot.  Kernels whose FIR is register-hungry (register-tiled
     // long filters) re-derive them at the top of every tile instead of keeping 8*SPL VGPRs live across the FIR

@@ -62,13 +62,30 @@ __device__ __forceinline__ float norm_ref(float2 v) {
 // ---------------------------------------------------------------- unpack (src/lib.rs:241-255)
 
 // one IEEE f32 division (+ one IEEE subtraction); hipcc's default f32 '/' is correctly rounded
+// Correctly rounded f / d for the small integers the sample formats produce, without the division sequence: q = f * RN(1/d),
+// then one residual step, e = fma(-q, d, f) (exact), q + e * RN(1/d) rounded once.  Verified against the IEEE quotient for
+// EVERY input of the three formats (256 / 256 / 65536 values; tests/test_oracle_golden.py restates the check on the CPU).
+__device__ __forceinline__ float div_small(float f, float d, float rd) {
+    const float q = f * rd;
+    const float e = __builtin_fmaf(-q, d, f);
+    return __builtin_fmaf(e, rd, q);
+}
+// one 8-bit pair component out of a packed word: the byte as f32 (v_cvt_f32_ubyteN), no table
+__device__ __forceinline__ float unpack_cs8_at(uint32_t w_flipped /* word ^ 0x80808080 */, int k) {
+    const float f = (float)((w_flipped >> (8 * k)) & 0xffu) - 128.0f;        // (b as i8) as f32, exact
+    return div_small(f, 127.0f, 1.0f / 127.0f);
+}
+__device__ __forceinline__ float unpack_cu8_at(uint32_t w, int k) {
+    const float f = (float)((w >> (8 * k)) & 0xffu);
+    return div_small(f, 255.0f, 1.0f / 255.0f) - 127.5f;
+}
 __device__ __forceinline__ float unpack_cs8(uint32_t b) { return (float)(int8_t)(uint8_t)b / 127.0f; }
 __device__ __forceinline__ float unpack_cu8(uint32_t b) {
     float q = (float)(uint8_t)b / 255.0f;
     return q - 127.5f;
 }
 __device__ __forceinline__ float unpack_cs16(uint32_t h) {
-    float q = (float)(int16_t)(uint16_t)h / 65535.0f;
+    const float q = div_small((float)(int16_t)(uint16_t)h, 65535.0f, 1.0f / 65535.0f);
     return q - 32767.5f;
 }
 

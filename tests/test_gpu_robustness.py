@@ -171,6 +171,45 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     assert_norms_close(ref, b[:ref.shape[0]], "jit")
 
 
+@pytest.mark.parametrize("fmt,lp,W,S,shift,hint", [
+    # the built-in cfg3' kernel's variant set on a short stream: packed pair FIR + row-aligned phase 1 + deferred FFT (two slots)
+    (0, (200_000, 32, 200), 128, 128, 280_000, (1, 256, 1, 8, 4, 2, 2 | (76 << 8), 0)),
+    (0, (200_000, 32, 200), 128, 128, 280_000, (1, 256, 1, 8, 4, 2, 1 | (12 << 8), 0)),
+    (3, (200_000, 32, 200), 128, 128, -77_000, (1, 256, 1, 8, 4, 2, 2 | (68 << 8), 0)),     # cs16: deferred FFT without fast phase 1
+    (1, (400_000, 16, 64), 64, 64, 120_000, (2, 512, 1, 8, 4, 2, 2 | (68 << 8), 0)),       # two windows per tile, 512 threads
+    # cfg4's: two outputs per lane as packed straight-line code, truncated outputs as snapshots; + deferred FFT on the first idle wave
+    (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 1024, 2, 4, 4, 2, 1 | (128 << 8), 0)),
+    (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 1024, 2, 4, 4, 2, 2 | (192 << 8), 0)),
+    (0, (2_000_000, 16, 256), 256, 256, 310_000, (1, 256, 2, 4, 4, 2, 2 | (192 << 8), 0)),  # other D / T / W, shift on, 256 threads
+    (2, (1_000_000, 8, 128), 128, 128, -5_000, (2, 512, 2, 4, 4, 2, 1 | (128 << 8), 0)),    # cu8, G = 2
+])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift, hint, epi):
+    """Every FixedGeo FLAGS_ variant the built-in kernels use (and neighbours of them on other shapes), forced through
+    qd_plan_options.tile_hint, against the generic kernel: same bytes for f32 norms, glyph codes and bucket digits — the
+    deferred-FFT path has its own wave-local FFT and epilogues (the bucket one in place), the packed-tile FIR its own
+    snapshot logic.  Ragged last tile included (the window count is not a multiple of the tile)."""
+    from test_gpu_parity import _signal, _to_format
+    if os.environ.get("QD_NO_FIXED"):
+        pytest.skip("QD_NO_FIXED=1 runs the generic kernels only")
+    D, T = lp[1], lp[2]
+    N = (38 * S + W) * D + T + 3              # 39 windows: a ragged last tile for G = 2
+    data = _to_format(_signal(np.random.default_rng(W + T + epi), N), fmt)
+    kw = dict(shift_hz=shift, lowpass=lp, width=W, stride=S, epilogue=epi)
+    if epi == 1:
+        kw["rng"] = (0.001, 0.5)
+    ref_plan = engine.Plan(fmt, 21_000_000, N, kernel_policy=engine.KERNEL_GENERIC, **kw)
+    var_plan = engine.Plan(fmt, 21_000_000, N, tile_hint=list(hint), **kw)
+    assert ref_plan.info.kernel_kind == 0 and var_plan.info.kernel_kind == 2
+    assert var_plan.info.tile_windows == hint[0] and var_plan.info.threads == hint[1]
+    a, b = ref_plan.run_host(data), var_plan.run_host(data)
+    assert a.shape == b.shape and a.shape[0] in (38, 39)         # bucket: lim / stride windows (src/fft.rs:86), one fewer than sparkfft counts here
+    assert a.tobytes() == b.tobytes(), (np.nonzero((a != b).reshape(a.shape[0], -1).any(axis=1))[0][:8],)
+    if epi == 0 and shift is None:
+        ref, _ = oracle.Chain.from_bytes(data, fmt, 21_000_000).lowpass(*lp).spark_fft(W, S, max_windows=40)
+        assert bits_equal(ref, b[:ref.shape[0]])
+
+
 def test_random_shapes_specialised_equals_generic(engine, oracle):
     """Fuzz: ~30 random chain shapes (all four formats, odd decimations, overlapping / gapped windows, 2..800 taps,
     some forced onto the register-tiled / wide-workgroup / 16-byte-row variants) — the plan-time specialised kernel

@@ -77,6 +77,11 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
             if rng.random() < 0.25 and D % 8 == 0 and T % 16 == 0:
                 tune = "%d:%d:%d:8:%d:%d" % (rng.integers(1, 4), rng.choice([256, 512, 1024]), rng.choice([1, 2]), rng.choice([2, 4]),
                                             rng.choice([1, 2]))
+            elif rng.random() < 0.35 and D % 8 == 0 and T % 8 == 0 and T >= 32:
+                # the FLAGS_ variants of the built-in kernels on shapes of the fuzzer's choosing: packed pair FIR (4), row-aligned
+                # phase 1 (8), deferred FFT (64, two slots), straight-line shared FIR (32), packed two-output tile (128)
+                flags, batch = [(4, 1), (12, 1), (68, 2), (76, 2), (32, 1), (128, 1), (192, 2), (4, 2)][int(rng.integers(0, 8))]
+                tune = "%d:%d:%d:4:4:2:%d:0" % (rng.integers(1, 3), rng.choice([256, 512, 1024]), 2 if flags & 128 else 1, batch | (flags << 8))
             epi = int(rng.choice([0, 0, 1, 2]))             # f32 norms / glyph codes / bucket digits
             outs, info = {}, {}
             for mode in ("0", "1"):
@@ -85,7 +90,14 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
                 if mode == "1" and tune:
                     os.environ["QD_TUNE"] = tune
                 try:
-                    p = Q.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=(1_000_000, D, T), width=W, stride=S, epilogue=epi)
+                    try:
+                        p = Q.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=(1_000_000, D, T), width=W, stride=S, epilogue=epi)
+                    except Q.QuadrsError as e:
+                        if "tile_hint" not in str(e) or "QD_TUNE" not in os.environ:
+                            raise
+                        os.environ.pop("QD_TUNE")            # a tiling this shape cannot take (LDS, geometry): the library's own choice
+                        tune = None
+                        p = Q.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=(1_000_000, D, T), width=W, stride=S, epilogue=epi)
                     outs[mode] = p.run_host(data)
                     info[mode] = (p.info.kernel_kind, p.info.tile_windows, p.info.threads)
                 except Q.QuadrsError as e:
