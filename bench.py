@@ -45,33 +45,36 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = "cfg3p"
 BPS = {0: 8, 1: 2, 2: 2, 3: 4}
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E data-sheet peak (MI355X_MICROARCH.md); ~6300 measured copy
-# VALU issue rates measured on MI355X (scripts/ubench_valu.hip): ns per wave-instruction per SIMD; v_pk_*_f32 measures 2.0,
-# i.e. no faster than two scalar ops, so a packed op is priced as two f32 slots
-T_F32_NS, T_F64_NS = 1.0, 2.0
+# VALU issue rates measured on MI355X at four waves per SIMD, chip unthrottled at 2.4 GHz (scripts/ubench_pk.hip,
+# profiles/r02/ubench_pk.log): ns per wave-instruction per SIMD.  A packed f32 op (two lane-operations) costs what an f64 op
+# costs and 5 % less than two scalar f32 ops, so the roof prices the FIR and the complex multiply as packed ops.
+T_F32_NS, T_F64_NS, T_PK_NS = 0.925, 1.76, 1.765
 LANES_PER_CHIP = 64 * 4 * 256          # 64 lanes x 4 SIMDs x 256 CUs
 
 
 def valu_ops_per_sample(cfg, nco_order):
-    """Arithmetic of the exact-order chain per INPUT sample (SURVEY 8(d) formula, refined to instruction classes):
-    f32 lane-operations and f64 lane-operations.  FIR: T/D taps per input sample, 2 components, separately rounded mul and
-    add; NCO (DESIGN.md section 4): 9 (first order) / 12 (second order) f64 ops + 2 f64->f32 converts, complex multiply 6 f32;
-    FFT ~5 W log2 W flops per window; |X| per bin: 2 converts, f64 mul + fma, an IEEE f64 sqrt (= 18 f64 issue slots,
-    measured 36 ns) and a convert; 8-bit unpack: ~2 integer ops per component, cs16: two IEEE f32 divides (~10 slots each)."""
+    """Arithmetic of the exact-order chain per INPUT sample (SURVEY 8(d) formula, refined to instruction classes): scalar f32
+    lane-operations, packed f32 operations (two lane-operations each) and f64-rate operations.  FIR: T/D taps per input sample,
+    one packed multiply and one packed add per tap (re and im, separately rounded); NCO: 9 (first order)
+    / 12 (second order) f64 ops + 2 f64->f32 converts, complex multiply 3 packed ops; FFT ~5 W log2 W flops per window; |X| per
+    bin: 2 converts, f64 mul + fma, an IEEE f64 sqrt (= 18 f64 issue slots) and a convert; unpack per sample (two components):
+    8-bit ~10 f32 ops (convert, bias, multiply by the reciprocal, residual, correction), cs16 12."""
     fc, D, T = cfg["lp"]
     W, S = cfg["W"], cfg["S"]
-    f32 = 4.0 * T / D + 5.0 * W * math.log2(W) / (S * D)
+    f32 = 5.0 * W * math.log2(W) / (S * D)
+    pk = 2.0 * T / D
     f64 = 23.0 * W / (S * D)
     if cfg["shift"] is not None:
-        f32 += 6.0
+        pk += 3.0
         f64 += (12.0 if nco_order == 2 else 9.0) + 2.0
-    f32 += {0: 0.0, 1: 4.0, 2: 6.0, 3: 24.0}[cfg["fmt"]]
-    return f32, f64
+    f32 += {0: 0.0, 1: 10.0, 2: 10.0, 3: 12.0}[cfg["fmt"]]
+    return f32, f64, pk
 
 
 def valu_roof_msamples(cfg, nco_order):
-    f32, f64 = valu_ops_per_sample(cfg, nco_order)
-    ns_per_lane_sample = f32 * T_F32_NS + f64 * T_F64_NS
-    return LANES_PER_CHIP / (ns_per_lane_sample * 1e-9) / 1e6, f32, f64
+    f32, f64, pk = valu_ops_per_sample(cfg, nco_order)
+    ns_per_lane_sample = f32 * T_F32_NS + f64 * T_F64_NS + pk * T_PK_NS
+    return LANES_PER_CHIP / (ns_per_lane_sample * 1e-9) / 1e6, f32 + 2.0 * pk, f64
 
 
 def synth_slab(torch, fmt, first, count, seed, device):
@@ -309,15 +312,16 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac},
                 "valu": {"achieved": kernel_msamples, "peak": valu_ms_roof, "unit": "Msamples/s", "frac": valu_frac,
                          "f32_ops_per_sample": f32_ops, "f64_ops_per_sample": f64_ops,
-                         "issue_ns_per_wave_instr": {"f32": T_F32_NS, "f64": T_F64_NS},
-                         "note": "exact-order arithmetic at the issue rates scripts/ubench_valu.hip measured; v_pk_*_f32 = two f32 slots"}}
+                         "issue_ns_per_wave_instr": {"f32": T_F32_NS, "f64": T_F64_NS, "packed_f32": T_PK_NS},
+                         "note": "exact-order arithmetic at the issue rates scripts/ubench_pk.hip measured (4 waves / SIMD, 2.4 GHz); FIR and complex multiply priced as packed ops"}}
         if bound == "hbm":
             roof.update(achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=hbm_frac)
         else:
-            # the VALU roof in TFLOP/s: every lane-operation of the count above is one flop (separately rounded mul / add, f64 ops
-            # priced at their issue cost of two f32 slots), so peak = lanes / 1 ns = 65.5 TFLOP/s of unfused f32 issue
-            slots = f32_ops + 2.0 * f64_ops
-            roof.update(achieved=kernel_msamples * 1e6 * slots / 1e12, peak=LANES_PER_CHIP / T_F32_NS * 1e9 / 1e12, unit="TFLOP/s", frac=valu_frac)
+            # the VALU roof in TFLOP/s: every lane-operation of the count above is one flop (separately rounded mul / add; f32 and
+            # f64 alike); `peak` is the same count at the roof's sample rate, i.e. what this instruction mix can reach at the
+            # measured issue rates — not the data-sheet FMA peak, which unfused exact-order arithmetic cannot approach
+            flops = f32_ops + f64_ops
+            roof.update(achieved=kernel_msamples * 1e6 * flops / 1e12, peak=valu_ms_roof * 1e6 * flops / 1e12, unit="TFLOP/s", frac=valu_frac)
         res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
                "outputs_finite": finite, "kernel_kind": int(info.kernel_kind), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
         if with_cpu:

@@ -1,6 +1,6 @@
 // Development probe: sustained rate of the FIR's packed multiply / add block (the asm statement of fir_tiled2_pk) per SIMD, at
 // 1, 2 and 4 waves per SIMD, against independent packed ops and scalar f32 ops.
-// build: hipcc --offload-arch=gfx950 -O2 scripts/ubench_pk.hip -o scripts/ubench_pk
+// build: hipcc --offload-arch=gfx950 -O2 -Wno-unused-value scripts/ubench_pk.hip -o scripts/ubench_pk
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
     v2f a0 = {seed, 0.f}, a1 = {0.f, seed};
     v2f x0 = {1.0f + threadIdx.x, 2.f}, x1 = {3.f, 4.f}, x2 = {5.f, 6.f}, x3 = {7.f, 8.f};
     v2f h01 = {seed, 0.5f}, h23 = {0.25f, 0.125f}, g01 = {0.3f, 0.7f}, g23 = {0.9f, 0.1f};
-    v2f t0, t1, t2, t3;
+    v2f t0 = {0.f, 0.f}, t1 = t0, t2 = t0, t3 = t0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -53,6 +53,20 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
                              "v_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8"
                              : "=&v"(t0.x), "=&v"(t1.x), "=&v"(t2.x), "=&v"(t3.x) : "v"(x0.x), "v"(h01.x), "v"(h23.x), "v"(g01.x), "v"(g23.x));
                 (void)p;
+            } else if (MODE == 5) {   // 16 v_fma_f64 in 4 independent chains
+                double *q = reinterpret_cast<double *>(&t0);
+                asm volatile("v_fma_f64 %0, %4, %5, %0\n\tv_fma_f64 %1, %4, %5, %1\n\tv_fma_f64 %2, %4, %5, %2\n\tv_fma_f64 %3, %4, %5, %3\n\t"
+                             "v_fma_f64 %0, %4, %5, %0\n\tv_fma_f64 %1, %4, %5, %1\n\tv_fma_f64 %2, %4, %5, %2\n\tv_fma_f64 %3, %4, %5, %3\n\t"
+                             "v_fma_f64 %0, %4, %5, %0\n\tv_fma_f64 %1, %4, %5, %1\n\tv_fma_f64 %2, %4, %5, %2\n\tv_fma_f64 %3, %4, %5, %3\n\t"
+                             "v_fma_f64 %0, %4, %5, %0\n\tv_fma_f64 %1, %4, %5, %1\n\tv_fma_f64 %2, %4, %5, %2\n\tv_fma_f64 %3, %4, %5, %3"
+                             : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(x0), "v"(h01));
+                (void)q;
+            } else if (MODE == 6) {   // 16 v_cvt_f32_f64
+                asm volatile("v_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3\n\tv_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3\n\t"
+                             "v_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3\n\tv_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3\n\t"
+                             "v_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3\n\tv_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3\n\t"
+                             "v_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3\n\tv_cvt_f32_f64 %0, %2\n\tv_cvt_f32_f64 %1, %3"
+                             : "=&v"(t0.x), "=&v"(t1.x) : "v"(x0), "v"(h01));
             } else {                  // MODE 4: one serial chain of dependent packed adds
                 asm volatile("v_pk_add_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1\n\t"
                              "v_pk_add_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1\n\t"
@@ -88,5 +102,7 @@ int main() {
     run<2>("independent v_pk_mul_f32 with op_sel", d);
     run<3>("scalar f32, 4 chains", d);
     run<4>("serial chain of v_pk_add_f32", d);
+    run<5>("v_fma_f64, 4 chains", d);
+    run<6>("v_cvt_f32_f64", d);
     return 0;
 }
