@@ -1009,11 +1009,12 @@ __device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row o
 // VALU.  Here every LDS offset is an immediate, a tap is used straight out of the register pair it arrives in (op_sel picks
 // the word for both halves of the packed multiply), and the tap blocks are shared between the two outputs (output 1 uses the
 // block output 0 used D/4 blocks earlier): 20 instructions per 4 samples (16 VALU, 3 LDS reads, 1 wait).
-template <class GeoT>
+template <class GeoT, int TURN>
 __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *h, float2 *full, const uint32_t *jm, float2 *snap) {
     constexpr uint32_t D = GeoT::D, T = GeoT::T, c = GeoT::c;
     constexpr uint32_t L = D + T, NB = L / 4, HB = T / 4, LAG = D / 4;      // sample blocks, tap blocks, output 1's lag in blocks
     constexpr int PF = 3, NS = PF + (int)LAG + 1;                            // sample / tap blocks in flight, live tap slots
+
     static_assert(GeoT::kFirTile == 2 && GeoT::PD == 2 * D && GeoT::pshift != 0xffffffffu && GeoT::kPad == 2, "two-output packed FIR: layout");
     static_assert(D % 4 == 0 && T % 4 == 0 && c % 4 == 0 && (T / 2) % 4 == 0 && NB > (uint32_t)PF && LAG >= 1 && LAG <= 8, "two-output packed FIR: geometry");
     v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
@@ -1046,6 +1047,11 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
         const float4 A = xa[b % PF], B = xb[b % PF];
         const v2f x0 = {A.x, A.y}, x1 = {A.z, A.w}, x2 = {B.x, B.y}, x3 = {B.z, B.w};
         v2f t0, t1, t2, t3;
+        // Two FIR waves share a SIMD and the issue arbiter serves the older one first: left alone, one wave runs at full speed,
+        // finishes at 60 % of the phase and leaves the other to run the tail on its own — a single wave cannot keep the VALU busy
+        // (2.2 against 1.77 ns per packed op, LDS waits exposed).  The two take turns at the higher priority, 8 blocks at a time,
+        // so both stay in flight to the end of the phase.
+        if constexpr (TURN >= 0) { if ((b % 8) == 0) { if (((b / 8) & 1u) != (uint32_t)TURN) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); } }
         if ((b < HB && cand(4 * b)) || (b >= LAG && cand(4 * (b - LAG)))) {  // compile-time: a snapshot tap starts at this block
             if (need_snap) {
                 if (b < HB && cand(4 * b)) { if (jm[0] == 4 * b) s0 = a0; }
@@ -1211,6 +1217,16 @@ constexpr bool defer_fft_ok(uint32_t nt) {
     }
 }
 
+// deferred FFT of one long window on four waves (see quad_fft_epilogue)
+template <class GeoT, bool HAS_FIR>
+constexpr bool quad_fft_ok(uint32_t nt) {
+    if constexpr (!GeoT::kFixed) return false;
+    else {
+        constexpr uint32_t GW = GeoT::G * GeoT::W, FL = GeoT::kPackedTile ? GW / 2 : GW;
+        return defer_fft_ok<GeoT, HAS_FIR>(nt) && GeoT::G == 1 && GeoT::W >= 256 && GeoT::layers >= 1 && GeoT::base_len >= 8 && FL + 4 * 64 <= nt;
+    }
+}
+
 // fast phase 1 (see k_chain): the tile starts on a row boundary whatever its index and is exactly RCH rows long
 template <int FMT, int NT, class GeoT>
 constexpr bool fast_p1_ok(int rch, bool whole, bool aligned) {
@@ -1245,6 +1261,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     // alternately).  The FFT is then wave-local — no workgroup barrier between its passes — and a tile costs the workgroup two
     // barriers and phase 1 + FIR of latency instead of four barriers and phase 1 + FIR + FFT + epilogue.
     constexpr bool kDefer = defer_fft_ok<GeoT, HAS_FIR>((uint32_t)NT);
+    constexpr bool kQuadFft = quad_fft_ok<GeoT, HAS_FIR>((uint32_t)NT);
     constexpr uint32_t kSlots = GeoT::kBatch;                 // FFT slots in LDS
     constexpr uint32_t kBatch = kDefer ? 1u : GeoT::kBatch;   // tiles per FFT batch
     constexpr uint32_t kLutElems = (FMT == 1 || FMT == 2) ? 256u : 0u;
@@ -1286,6 +1303,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     {
         const uint32_t n_tw = W - geo.base_len;               // 3*(base + 4*base + ...) = W - base
         for (uint32_t i = tid; i < n_tw; i += NT) twl[i] = P.tw[i];
+        if (tid == 0) bmeta[0] = 0;                           // arrival counter of the four-wave deferred FFT (see quad_fft_epilogue)
         // ... and the taps: the FIR loop then contains LDS reads only, so its waits are counted
         // lgkmcnt(N) instead of a full drain per batch (scalar loads share that counter and return
         // out of order, which forces lgkmcnt(0)).
@@ -1446,6 +1464,83 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             }
         }
     };
+    // The same on FOUR waves, for one long window (W >= 256): Radix4's last layer combines four contiguous sub-transforms of W/4
+    // points, and everything below it stays inside one sub-transform — so wave v transforms quarter v on its own (no workgroup
+    // barrier, the FIR waves run on), the four meet ONCE at an arrival counter in LDS, and each then takes a quarter of the last
+    // layer's butterflies: butterfly i yields bins i, i + W/4, i + W/2, i + 3W/4, which after the fftshift are the outputs at the
+    // same four places in rotated order, so norms / glyph codes go straight from registers to HBM.  A 1024-point window costs
+    // ~1/4 of the single-wave latency — short enough to hide under the FIR (cfg4), where the single wave was the long pole.
+    uint32_t quad_gen = 0;                                                // syncs passed so far (uniform over the four waves)
+    auto quad_fft_epilogue = [&](float2 *fbp, uint64_t pw0, uint32_t v) {
+        uint32_t lane = tid & 63u;
+        asm volatile("" : "+v"(lane));
+        auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+        const uint32_t Wq = geo.W >> 2, base = geo.base_len;
+        float2 *sub = fbp + (size_t)v * Wq;
+        for (uint32_t t = lane; t < Wq / base; t += 64) {
+            float2 *d = sub + (size_t)t * base;
+            if (base == 16) {
+                float2 x[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] = d[i];
+                bf16(x, P.tw16_1, P.tw16_2, P.tw16_3, P.root2);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d[i] = x[i];
+            } else {
+                float2 x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = d[i];
+                bf8(x, P.root2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] = x[i];
+            }
+        }
+        uint32_t cols = base, log_cols = geo.log_base;
+        const float2 *tw = twl;
+        for (uint32_t layer = 0; layer + 1 < geo.layers; ++layer) {
+            wsync();
+            for (uint32_t t = lane; t < Wq / 4; t += 64) {
+                const uint32_t chunk = t >> log_cols, i = t & (cols - 1);
+                float2 *d = sub + (size_t)chunk * 4 * cols + i;
+                float2 s0 = d[0];
+                float2 s1 = cmul(d[cols], tw[3 * i]);
+                float2 s2 = cmul(d[2 * cols], tw[3 * i + 1]);
+                float2 s3 = cmul(d[3 * cols], tw[3 * i + 2]);
+                bf4(s0, s1, s2, s3);
+                d[0] = s0; d[cols] = s1; d[2 * cols] = s2; d[3 * cols] = s3;
+            }
+            tw += 3 * cols;
+            cols *= 4;
+            log_cols += 2;
+        }
+        // the four waves meet: this wave's stores are issued before its arrival (LDS executes one wave's operations in order), and
+        // nothing after the wait is read early
+        ++quad_gen;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(&bmeta[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&bmeta[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * quad_gen) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // last layer (cols == W/4) + epilogue, butterflies [v W/16, (v+1) W/16)
+        const uint64_t wrel = pw0 - P.out_window0;
+        float *outf = reinterpret_cast<float *>(P.out) + (wrel << geo.logW);
+        uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << geo.logW);
+        for (uint32_t t = lane; t < Wq / 4; t += 64) {
+            const uint32_t i = v * (Wq / 4) + t;
+            const float2 *d = fbp + i;
+            float2 s0 = d[0];
+            float2 s1 = cmul(d[Wq], tw[3 * i]);
+            float2 s2 = cmul(d[2 * Wq], tw[3 * i + 1]);
+            float2 s3 = cmul(d[3 * Wq], tw[3 * i + 2]);
+            bf4(s0, s1, s2, s3);
+            // output o = i + k W/4 is bin o ^ (W/2) = i + ((k + 2) & 3) W/4
+            const float n0 = norm_ref(s2), n1 = norm_ref(s3), n2 = norm_ref(s0), n3 = norm_ref(s1);
+            if (P.epi == 0) { outf[i] = n0; outf[i + Wq] = n1; outf[i + 2 * Wq] = n2; outf[i + 3 * Wq] = n3; }
+            else {
+                outb[i] = glyph_code(n0, P.rmin, P.rmax, P.gstep); outb[i + Wq] = glyph_code(n1, P.rmin, P.rmax, P.gstep);
+                outb[i + 2 * Wq] = glyph_code(n2, P.rmin, P.rmax, P.gstep); outb[i + 3 * Wq] = glyph_code(n3, P.rmin, P.rmax, P.gstep);
+            }
+        }
+    };
     uint32_t bslot = 0;      // parked tiles of the current FFT batch (wave-uniform)
     QD_STAMP_DECL
     QD_STAMP_START();
@@ -1598,7 +1693,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                         for (int r = 0; r < 2; ++r) { const uint32_t j2 = (W - (k0 + r)) * D + T / 2; jm[r] = j2 < T ? j2 : T; }
                         float2 full[2], snp[2];
                         const uint32_t q0 = g * S + k0;
-                        fir_tiled2_pk<GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / 2)), tapl, full, jm, snp);
+                        if ((tid >> 8) & 1u) fir_tiled2_pk<GeoT, 1>(raw + (q0 * D + GeoT::kPad * (q0 / 2)), tapl, full, jm, snp); else fir_tiled2_pk<GeoT, 0>(raw + (q0 * D + GeoT::kPad * (q0 / 2)), tapl, full, jm, snp);
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
                             const uint32_t k = k0 + r;
@@ -1614,6 +1709,11 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                     const float2 v = QD_DBG(P, 2) ? rp[0] : fir_pair<GeoT>(rp, jmax, tapl);      // dbg: timing-only ablation
                     const uint32_t xx = k & ((1u << log_width_d) - 1), yy = k >> log_width_d;
                     fb_cur[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
+                }
+            } else if (kQuadFft && P.epi != 2) {               // one long window: four spare waves share its FFT + epilogue
+                if ((tid >> 6) < FL / 64 + 4 && dprev_valid) {
+                    __builtin_amdgcn_s_setprio(3);
+                    quad_fft_epilogue(fb_prev, dprev_w0, (tid >> 6) - FL / 64);
                 }
             } else if ((tid >> 6) == FL / 64 && dprev_valid) { // the first spare wave: previous tile's FFT + epilogue
                 __builtin_amdgcn_s_setprio(3);                 // one wave's serial work next to FIR waves on its SIMD: it goes first
@@ -1796,7 +1896,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 float2 full[R], snp[R];
                 {
                     const uint32_t q0 = g * S + k0;
-                    if constexpr (GeoT::kPackedTile) fir_tiled2_pk<GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), tapl, full, jm, snp);
+                    if constexpr (GeoT::kPackedTile) { if ((tid >> 8) & 1u) fir_tiled2_pk<GeoT, 1>(raw + (q0 * D + GeoT::kPad * (q0 / R)), tapl, full, jm, snp); else fir_tiled2_pk<GeoT, 0>(raw + (q0 * D + GeoT::kPad * (q0 / R)), tapl, full, jm, snp); }
                     else fir_tiled<R, GeoT>(raw + (q0 * D + GeoT::kPad * (q0 / R)), jm, tapl, full, snp);
                 }
 #pragma unroll
@@ -1999,6 +2099,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     }
     if constexpr (kDefer) {
         constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct, FL = GeoT::kPackedTile ? GW / 2 : GW;
+        if (kQuadFft && P.epi != 2) {
+            if (dprev_valid && (tid >> 6) >= FL / 64 && (tid >> 6) < FL / 64 + 4) quad_fft_epilogue(fb0 + (size_t)(dpar ^ 1u) * GW, dprev_w0, (tid >> 6) - FL / 64);
+        } else
         if (dprev_valid && (tid >> 6) == FL / 64) wave_fft_epilogue(fb0 + (size_t)(dpar ^ 1u) * GW, dprev_w0, dprev_gcnt);
     }
     if (dyn && tid == 0) {       // the last workgroup to leave re-arms the queue for the next launch
