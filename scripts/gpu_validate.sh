@@ -1,4 +1,5 @@
 #!/bin/bash
+# The round-end validation in one gpurun call: GPU suite under the three kernel policies, default bench, 2-rank rehearsal.
 mkdir -p gpurun_out
 step() { "$@"; rc=$?; if [ $rc -ge 124 ]; then echo "step killed rc=$rc: $*"; exit $rc; fi; return $rc; }
 step timeout -k 10 600 python -m pytest tests -m gpu -q -x > gpurun_out/r2_tests.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r2_tests.log
