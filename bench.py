@@ -110,6 +110,45 @@ def synth_slab(torch, fmt, first, count, seed, device):
     return out
 
 
+def sample_power(step, torch, seconds):
+    """AFTER the timed region: keep the kernel running back to back for a few seconds and read the board's package power and
+    shader clock from rocm-smi meanwhile (informational: says whether the kernel runs at the power cap — DESIGN.md section 7).
+    Returns None where rocm-smi is missing or prints something else."""
+    import re
+    import subprocess
+    import threading
+    samples = []
+    stop = threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            w = re.search(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+            c = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
+            m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+            if w and c:
+                samples.append((float(w.group(1)), int(c.group(1)), float(m.group(1)) if m else None))
+            stop.wait(0.3)
+
+    th = threading.Thread(target=poll, daemon=True)
+    t_end = time.perf_counter() + seconds
+    th.start()
+    while time.perf_counter() < t_end:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=15)
+    samples = samples[1:] if len(samples) > 2 else samples          # the first reading may predate the load
+    if not samples:
+        return None
+    return {"watts": max(s[0] for s in samples), "sclk_mhz": min(s[1] for s in samples), "cap_watts": samples[-1][2], "samples": len(samples),
+            "note": "rocm-smi while the kernel runs back to back, after the timed region: highest package power, lowest shader clock seen"}
+
+
 def cpu_baseline(cfg, slab_bytes, target_s=12.0):
     """Times the CPU oracle (reference-literal cost class) on a bounded number of windows."""
     from oracle import oracle as O
@@ -280,6 +319,9 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
     finite = bool(torch.isfinite(out).all().item())
+    power = None
+    if rank == 0 and world == 1 and getattr(args, "power_sample", False):
+        power = sample_power(step, torch, max(1.0, 2.5))
 
     res = None
     if rank == 0:
@@ -322,6 +364,8 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
             # measured issue rates — not the data-sheet FMA peak, which unfused exact-order arithmetic cannot approach
             flops = f32_ops + f64_ops
             roof.update(achieved=kernel_msamples * 1e6 * flops / 1e12, peak=valu_ms_roof * 1e6 * flops / 1e12, unit="TFLOP/s", frac=valu_frac)
+        if power:
+            roof["power"] = power
         res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
                "outputs_finite": finite, "kernel_kind": int(info.kernel_kind), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
         if with_cpu:
@@ -423,6 +467,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configs (default one-GPU run only)")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock reading after the timed region (one-GPU runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed launches before the warmup steps (clock ramp)")
     ap.add_argument("--samples-log2", type=int, default=None, help="override samples per GPU (2^k); rehearsals only")
@@ -460,8 +505,10 @@ def main():
     cfg = dict(WORKLOADS[args.workload])
     if args.samples_log2 is not None:
         cfg["n"] = 1 << args.samples_log2
+    args.power_sample = world == 1 and not args.no_power and not args.stub
     main_res = measure(args, args.workload, cfg, rank, world, device, dist, args.steps, args.warmup,
                        with_cpu=(world == 1 and not args.no_cpu_baseline))
+    args.power_sample = False
     others = None
     if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
         # the other BASELINE configs, briefly (same protocol, fewer steps, no CPU leg): parity-test cases first, bench lines second
