@@ -1111,59 +1111,6 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
     snap[1] = make_float2(s1.x, s1.y);
 }
 
-// Truncated tail outputs, packed: see fir_prefix.  Eight taps per trip (four sample reads, two tap reads, one asm statement of
-// 16 packed instructions), the next trip's reads in flight; a lane drops out at its own jmax (a multiple of 8).
-template <class GeoT>
-__device__ __forceinline__ float2 fir_prefix_pk(const float2 *raw, uint32_t t0, uint32_t jmax, const float *h) {
-    constexpr uint32_t T = GeoT::T;
-    static_assert(GeoT::kPad == 2 && GeoT::pshift != 0xffffffffu && (GeoT::PD % 8) == 0, "packed prefix: 16-byte rows, blocks of 8 inside a pad period");
-    v2f acc = {0.f, 0.f};
-    uint32_t jhi = jmax;                                   // longest prefix in the wave bounds the loop
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)jhi, off); jhi = o > jhi ? o : jhi; }
-    float4 xa[4], xb[4], ha[2], hb[2];
-    auto load = [&](uint32_t jb, float4 *x, float4 *hh) {   // reads past a lane's own jmax stay inside its T-sample span
-        const uint32_t t = t0 + jb;
-        // t is a multiple of 8 and the pad term a multiple of 2 elements: 16-byte aligned (said out loud, or hipcc splits the reads)
-        const float4 *pp = static_cast<const float4 *>(__builtin_assume_aligned(raw + (t + GeoT::kPad * (t >> GeoT::pshift)), 16));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = pp[i];
-        const float4 *hp = static_cast<const float4 *>(__builtin_assume_aligned(h + jb, 16));
-        hh[0] = hp[0]; hh[1] = hp[1];
-    };
-    auto mac = [&](uint32_t jb, const float4 *x, const float4 *hh) {
-        if (jb < jmax) {                                   // whole block in or out (jmax is a multiple of 8)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const v2f x0 = {x[2 * q].x, x[2 * q].y}, x1 = {x[2 * q].z, x[2 * q].w}, x2 = {x[2 * q + 1].x, x[2 * q + 1].y}, x3 = {x[2 * q + 1].z, x[2 * q + 1].w};
-                const v2f h01 = {hh[q].x, hh[q].y}, h23 = {hh[q].z, hh[q].w};
-                v2f p0, p1;
-                asm volatile("v_pk_mul_f32 %1, %3, %7 op_sel_hi:[1,0]\n\t"
-                             "v_pk_mul_f32 %2, %4, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                             "v_pk_add_f32 %0, %0, %1\n\t"
-                             "v_pk_mul_f32 %1, %5, %8 op_sel_hi:[1,0]\n\t"
-                             "v_pk_add_f32 %0, %0, %2\n\t"
-                             "v_pk_mul_f32 %2, %6, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                             "v_pk_add_f32 %0, %0, %1\n\t"
-                             "v_pk_add_f32 %0, %0, %2"
-                             : "+v"(acc), "=&v"(p0), "=&v"(p1)
-                             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23));
-            }
-        }
-    };
-    load(0, xa, ha);
-#pragma unroll 1
-    for (uint32_t jb = 0; jb < jhi; jb += 16) {            // two 8-tap blocks per trip, the next one always in flight
-        if (jb + 8 < T) load(jb + 8, xb, hb);
-        mac(jb, xa, ha);
-        __builtin_amdgcn_sched_barrier(0);
-        if (jb + 16 < T) load(jb + 16, xa, ha);
-        mac(jb + 8, xb, hb);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return make_float2(acc.x, acc.y);
-}
-
 // Truncated tail outputs on spare lanes (register-tiled kernels whose workgroup has idle waves in the FIR phase):
 // the reference's per-read_at truncation makes the last kNtrunc outputs of a window PREFIXES of the full chain
 // (jmax = T/2 + m*D taps).  Computing them as accumulator snapshots inside the main loop makes the one wave that

@@ -24,14 +24,8 @@ struct FixedEntry {
 
 #define QD_FIXED(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NAME) \
     { F, NCO, W, S, D, T, G, LB, qd::kThreads, 1, 1, 0, RCH, WHOLE, 8, 1, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G>, true, RCH, WHOLE, true, LB>, NAME }
-#define QD_FIXED_B(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, BATCH, NAME) \
-    { F, NCO, W, S, D, T, G, LB, qd::kThreads, 1, BATCH, 0, RCH, WHOLE, 8, 1, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, 8, 1, 1, BATCH>, true, RCH, WHOLE, true, LB>, NAME }
-#define QD_FIXED_F(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, PAD, FLAGS, NAME) \
-    { F, NCO, W, S, D, T, G, LB, qd::kThreads, PAD, 1, FLAGS, RCH, WHOLE, 8, 1, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, 8, 1, PAD, 1, FLAGS>, true, RCH, WHOLE, true, LB>, NAME }
 #define QD_FIXED_FB(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, PAD, BATCH, FLAGS, NAME) \
     { F, NCO, W, S, D, T, G, LB, qd::kThreads, PAD, BATCH, FLAGS, RCH, WHOLE, 8, 1, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, 8, 1, PAD, BATCH, FLAGS>, true, RCH, WHOLE, true, LB>, NAME }
-#define QD_FIXED_NT(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, FIRR, PAD, NAME) \
-    { F, NCO, W, S, D, T, G, LB, NT, PAD, 1, 0, RCH, WHOLE, FIRB, FIRR, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, FIRB, FIRR, PAD>, true, RCH, WHOLE, true, LB, NT>, NAME }
 
 #define QD_FIXED_NTF(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, FIRR, PAD, FLAGS, NAME) \
     { F, NCO, W, S, D, T, G, LB, NT, PAD, 1, FLAGS, RCH, WHOLE, FIRB, FIRR, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, FIRB, FIRR, PAD, 1, FLAGS>, true, RCH, WHOLE, true, LB, NT>, NAME }
