@@ -119,6 +119,18 @@ def sample_power(step, torch, seconds):
     import threading
     samples = []
     stop = threading.Event()
+    # which rocm-smi card is torch's device 0?  match the PCI bus id; fall back to the first card listed
+    card = None
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        bus = subprocess.run(["rocm-smi", "--showbus"], capture_output=True, text=True, timeout=10).stdout
+        for mm in re.finditer(r"GPU\[(\d+)\]\s*:\s*PCI Bus:\s*([0-9A-Fa-f:.]+)", bus):
+            if mm.group(2).lower().startswith(want):
+                card = mm.group(1)
+    except Exception:
+        card = None
+    pre = r"GPU\[%s\]\s*:\s*" % card if card is not None else ""
 
     def poll():
         while not stop.is_set():
@@ -126,9 +138,9 @@ def sample_power(step, torch, seconds):
                 txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
             except Exception:
                 return
-            w = re.search(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", txt)
-            c = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
-            m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+            w = re.search(pre + r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+            c = re.search(pre + r"sclk clock level:.*?\((\d+)Mhz\)", txt)
+            m = re.search(pre + r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
             if w and c:
                 samples.append((float(w.group(1)), int(c.group(1)), float(m.group(1)) if m else None))
             stop.wait(0.3)
@@ -146,6 +158,7 @@ def sample_power(step, torch, seconds):
     if not samples:
         return None
     return {"watts": max(s[0] for s in samples), "sclk_mhz": min(s[1] for s in samples), "cap_watts": samples[-1][2], "samples": len(samples),
+            "card": card if card is not None else "first listed",
             "note": "rocm-smi while the kernel runs back to back, after the timed region: highest package power, lowest shader clock seen"}
 
 
