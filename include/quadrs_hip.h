@@ -171,8 +171,12 @@ typedef struct {
     int32_t  shard_device[QD_MAX_SHARDS];   /* HIP device of shard g (a device may serve several shards) */
     uint32_t tile_hint[8];       /* tuning: force a plan-time build with this tiling — windows per tile, threads (256 /
                                     512 / 1024), FIR outputs per lane, FIR block taps, waves per SIMD the build is register-
-                                    budgeted for, LDS pad elements per row (1 / 2), tiles per FFT batch, workgroups per CU;
-                                    all 0: the library's own choice */
+                                    budgeted for, LDS pad elements per row (1 / 2), FFT slots (tiles per FFT batch; 2 with the
+                                    deferred FFT) in bits 0-7 of slot 6 and the kernel variant bits in bits 8-15 (1 planar LDS
+                                    tile, 2 taps baked into the code, 4 packed lane-per-output FIR, 8 row-aligned phase 1, 16
+                                    packed span FIR, 32 straight-line shared FIR, 64 deferred FFT, 128 packed two-output tile FIR;
+                                    a bit a shape cannot take is ignored), workgroups per CU; all 0: the library's own choice.
+                                    Every tiling and variant computes the same bytes */
 } qd_plan_options;
 
 int qd_plan_create(const qd_chain_desc *desc, qd_plan **plan);
