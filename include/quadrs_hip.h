@@ -176,7 +176,8 @@ typedef struct {
                                     tile, 2 taps baked into the code, 4 packed lane-per-output FIR, 8 row-aligned phase 1, 16
                                     packed span FIR, 32 straight-line shared FIR, 64 deferred FFT, 128 packed two-output tile FIR;
                                     a bit a shape cannot take is ignored), workgroups per CU; all 0: the library's own choice.
-                                    Every tiling and variant computes the same bytes */
+                                    Every variant of one workgroup size computes the same bytes; with a shift stage, tilings of different workgroup
+                                    size may round ~1e-8 of the NCO multipliers the other way (DESIGN.md sections 3.1, 4) */
 } qd_plan_options;
 
 int qd_plan_create(const qd_chain_desc *desc, qd_plan **plan);
