@@ -48,7 +48,7 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
+def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=False):
     """Random chain shapes through the plan-time compiler (QD_JIT=1; a quarter of them with a QD_TUNE tiling that
     exercises the register-tiled FIR / 16-byte LDS rows / wide workgroups) against the generic kernel (QD_JIT=0),
     bit for bit; with `oracle` (tests only) the first windows are also checked against the CPU oracle: bit-exact without
@@ -65,6 +65,11 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
             S = int(rng.choice([W, W, max(1, W // 2), max(1, W // 4), int(rng.integers(1, 2 * W + 1))]))
             D = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 32, 64]))
             T = int(rng.choice([2, 8, 9, 16, 40, 48, 64, 100, 128, 200, 256, 400, 512, 800]))
+            if variants_only:                       # geometries the FLAGS_ variants apply to, every shape with a variant tiling
+                D = int(rng.choice([8, 16, 32, 64]))
+                T = int(rng.choice([32, 40, 48, 64, 96, 128, 200, 256, 400, 512, 800]))
+                if rng.random() < 0.5:
+                    S = W
             if (W * D + T) * 8 * 1.2 > 150 * 1024:
                 continue
             shift = None if rng.random() < 0.25 else int(rng.integers(-3_000_000, 3_000_000))
@@ -74,10 +79,10 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None):
             if fmt == 0:
                 data = (rng.standard_normal((N, 2)).astype(np.float32) * 0.05).view(np.uint8).reshape(-1)
             tune = None
-            if rng.random() < 0.25 and D % 8 == 0 and T % 16 == 0:
+            if not variants_only and rng.random() < 0.25 and D % 8 == 0 and T % 16 == 0:
                 tune = "%d:%d:%d:8:%d:%d" % (rng.integers(1, 4), rng.choice([256, 512, 1024]), rng.choice([1, 2]), rng.choice([2, 4]),
                                             rng.choice([1, 2]))
-            elif rng.random() < 0.35 and D % 8 == 0 and T % 8 == 0 and T >= 32:
+            elif (variants_only or rng.random() < 0.35) and D % 8 == 0 and T % 8 == 0 and T >= 32:
                 # the FLAGS_ variants of the built-in kernels on shapes of the fuzzer's choosing: packed pair FIR (4), row-aligned
                 # phase 1 (8), deferred FFT (64, two slots), straight-line shared FIR (32), packed two-output tile (128)
                 flags, batch = [(4, 1), (12, 1), (68, 2), (76, 2), (32, 1), (128, 1), (192, 2), (4, 2)][int(rng.integers(0, 8))]
