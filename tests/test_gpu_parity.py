@@ -352,22 +352,28 @@ def test_fused_write_blocks(engine, oracle, fmt, D, T, B, shift):
     assert bits_equal(part, got[B:3 * B])
 
 
-def test_window_subranges_and_slabs_concatenate(engine, oracle):
+@pytest.mark.parametrize("shift,lp,W,S", [(280000, (200_000, 32, 400), 64, 16),          # README FSK chain: shared FIR, straight-line kernel
+                                          (280000, (200_000, 32, 200), 128, 128),        # cfg3': packed FIR, row-aligned phase 1, deferred FFT
+                                          (None, (5_000_000, 8, 512), 1024, 1024)])      # cfg4: packed tile, four-wave deferred FFT
+def test_window_subranges_and_slabs_concatenate(engine, oracle, shift, lp, W, S):
     """§8(e): windows are independent; a slab [src_first, ...) + absolute indices reproduces the
-    whole-stream run bit for bit — including seams and an unaligned (odd) slab start."""
+    whole-stream run bit for bit — including seams and an unaligned (odd) slab start.  On the built-in kernels of the
+    BASELINE shapes: sub-ranges start in the middle of a tile and end on ragged ones."""
     rng = np.random.default_rng(5)
+    D, T = lp[1], lp[2]
     N = 600_000
     x = _signal(rng, N)
     data = x.tobytes()
-    p = engine.Plan(0, 21_000_000, N, shift_hz=280000, lowpass=(200_000, 32, 400), width=64, stride=16)
+    p = engine.Plan(0, 21_000_000 if shift is not None else 100_000_000, N, shift_hz=shift, lowpass=lp, width=W, stride=S)
     whole = p.run_host(data)
+    assert p.n_windows >= 70
     for shards in (2, 3, 8):
         bounds = np.linspace(0, p.n_windows, shards + 1).astype(np.int64)
         parts = []
         for g in range(shards):
             w0, w1 = int(bounds[g]), int(bounds[g + 1])
             first, count = p.src_range(w0, w1 - w0)
-            assert count == (w1 - w0 - 1) * 16 * 32 + 64 * 32 + 400            # halo (W-S)*D + T past the last step
+            assert count == (w1 - w0 - 1) * S * D + W * D + T                  # halo (W-S)*D + T past the last step
             slab = x[first:first + count].tobytes()
             parts.append(p.run_host(slab, w0, w1 - w0, src_first=first))
         assert bits_equal(np.concatenate(parts), whole), shards
