@@ -180,6 +180,7 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     # cfg4's: two outputs per lane as packed straight-line code, truncated outputs as snapshots; + deferred FFT on the first idle wave
     (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 1024, 2, 4, 4, 2, 1 | (128 << 8), 0)),
     (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 1024, 2, 4, 4, 2, 2 | (192 << 8), 0)),
+    (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 1024, 2, 4, 4, 2, 2 | (200 << 8), 0)),     # the built-in cfg4 kernel's set
     (0, (2_000_000, 16, 256), 256, 256, 310_000, (1, 256, 2, 4, 4, 2, 2 | (192 << 8), 0)),  # other D / T / W, shift on, 256 threads
     (2, (1_000_000, 8, 128), 128, 128, -5_000, (2, 512, 2, 4, 4, 2, 1 | (128 << 8), 0)),    # cu8, G = 2
 ])
