@@ -1,0 +1,35 @@
+"""Development: race hunt by repetition — the built-in kernels of the BASELINE shapes (deferred FFT, tile queue, LDS arrival
+counter) run many times over one input; every output must equal the first run's, byte for byte.
+usage: python scripts/determinism_soak.py [runs]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+import quadrs_amd as Q
+
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+dev = torch.device("cuda", 0)
+for name, log2, epi in (("cfg3p", 27, 0), ("cfg3p", 27, 2), ("cfg4", 28, 0), ("cfg4", 28, 1), ("cfg3", 27, 0), ("cfg2", 26, 0)):
+    cfg = dict(bench.WORKLOADS[name]); cfg["n"] = 1 << log2
+    if name == "cfg4":
+        src = torch.empty(cfg["n"], 2, dtype=torch.float32, device=dev)
+        Q.gen_device([(k - 32) * 1_562_500 + 390_625 for k in range(64)], cfg["sr"], 0, src)
+    else:
+        src = bench.synth_slab(torch, cfg["fmt"], 0, cfg["n"], 0x5EED0002, dev)
+    kw = dict(rng=(0.001, 0.5)) if epi == 1 else {}
+    p = Q.Plan(cfg["fmt"], cfg["sr"], cfg["n"], shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"], epilogue=epi, **kw)
+    shape = (p.n_windows,) if epi == 2 else (p.n_windows, cfg["W"])
+    dt = torch.float32 if epi == 0 else torch.uint8
+    ref = torch.empty(shape, dtype=dt, device=dev)
+    out = torch.empty(shape, dtype=dt, device=dev)
+    p.run_device(src, ref)
+    torch.cuda.synchronize()
+    bad = 0
+    for r in range(runs):
+        out.zero_()
+        p.run_device(src, out)
+        if not torch.equal(out.view(torch.uint8), ref.view(torch.uint8)):
+            bad += 1
+    print(f"{name} epilogue {epi}: kind {p.info.kernel_kind}, {p.n_windows} windows, {runs} runs, differing runs: {bad}", flush=True)
+    del src, ref, out
