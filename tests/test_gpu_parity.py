@@ -387,6 +387,24 @@ def test_window_subranges_and_slabs_concatenate(engine, oracle, shift, lp, W, S)
         p.run_host(data, p.n_windows - 1, 2)                                            # past the sink's loop
 
 
+@pytest.mark.parametrize("name", ["cfg2", "cfg3p", "cfg4"])
+def test_full_size_census(engine, oracle, name):
+    """EVERY window of the workload at BASELINE.json's full size against the oracle (all host cores, a few seconds): the chains
+    without a shift stage must be identical in every bit; with one, all but a handful of windows (an NCO multiplier within
+    ~1e-8 f32-ulp of a rounding boundary may round the other way: DESIGN.md section 4), and those within a fraction of an ulp of
+    the window maximum.  cfg3 (16.8 M windows, minutes of host time) is run by scripts/full_census.py: profiles/r02/full_census.log."""
+    import bench
+    from oracle import oracle as O
+    from util import full_size_census
+    total, kind, nw, nb, worst, first, t_gpu, t_cpu, cores = full_size_census(engine, O, bench, name)
+    record_observed(f"census {name}", windows=int(total), windows_differing=int(nw), bins_differing=int(nb), worst_ulp_of_window_max=float(worst),
+                    oracle_seconds=round(t_cpu, 1), threads=int(cores))
+    if bench.WORKLOADS[name]["shift"] is None:
+        assert nw == 0, (nw, nb, worst, first)
+    else:
+        assert nw <= max(8, total // 100000) and worst <= 1.0, (nw, nb, worst, first)
+
+
 def test_device_resident_run_equals_host_run(engine):
     import torch
     rng = np.random.default_rng(9)

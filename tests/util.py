@@ -138,3 +138,67 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=Fa
             else:
                 os.environ[k] = v
     return checked, bad
+
+
+def full_size_census(Q, O, bench, name):
+    """EVERY window of BASELINE workload `name` at its full size: HIP chain kernel against the CPU oracle in its cheapest exact
+    form (FIR at the decimated positions only, same products, same order) on all host cores, same input bytes, absolute sample
+    indices.  Returns (n_windows, kernel_kind, windows_differing, bins_differing, worst deviation in ulp of the window maximum,
+    first differing window or None, seconds on the GPU side, seconds in the oracle, threads)."""
+    import concurrent.futures as cf
+    import os
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    cores = max(1, min(len(os.sched_getaffinity(0)), 32))
+    cfg = bench.WORKLOADS[name]
+    t0 = time.perf_counter()
+    if name == "cfg4":
+        src = torch.empty(cfg["n"], 2, dtype=torch.float32, device=dev)
+        tones = [(k - 32) * 1_562_500 + 390_625 for k in range(64)]
+        for a in range(0, cfg["n"], 1 << 28):
+            Q.gen_device(tones, cfg["sr"], a, src[a:a + (1 << 28)])
+    else:
+        src = bench.synth_slab(torch, cfg["fmt"], 0, cfg["n"], 0x5EED0002, dev)
+    p = Q.Plan(cfg["fmt"], cfg["sr"], cfg["n"], shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
+    out = torch.empty(p.n_windows, cfg["W"], dtype=torch.float32, device=dev)
+    p.run_device(src, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    host = src.view(torch.uint8).reshape(-1).cpu().numpy()
+    del src, out
+    torch.cuda.empty_cache()
+    t_gpu = time.perf_counter() - t0
+    # the oracle on the very same bytes; no copy of the slab (the C side reads through the pointer)
+    ch = O.Chain()
+    ch._node = O.lib().qo_source_mem(O._p(host), host.size, cfg["fmt"], cfg["sr"])
+    ch._keep.append(host)
+    if cfg["shift"] is not None:
+        ch = ch.shift(cfg["shift"])
+    ch = ch.lowpass(*cfg["lp"])
+    total = O.lib().qo_spark_window_count(ch.len(), cfg["W"], cfg["S"])
+    assert total == p.n_windows, (total, p.n_windows)
+    piece = 8192
+    jobs = [(a, min(piece, total - a)) for a in range(0, total, piece)]
+
+    def work(job):
+        a, n = job
+        ref, _ = ch.spark_fft(cfg["W"], cfg["S"], first_window=a, max_windows=n, want_codes=False)
+        g = got[a:a + n]
+        ne = ref.view(np.uint32) != g.view(np.uint32)
+        if not ne.any():
+            return 0, 0, 0.0, None
+        scale = np.spacing(np.abs(ref).max(axis=1, keepdims=True).astype(np.float32)).astype(np.float64)
+        err = (np.abs(ref.astype(np.float64) - g.astype(np.float64)) / scale).max()
+        rows = np.nonzero(ne.any(axis=1))[0]
+        return len(rows), int(ne.sum()), float(err), int(a + rows[0])
+
+    nw = nb = 0
+    worst, first = 0.0, None
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        for a, b, err, f in ex.map(work, jobs):
+            nw += a; nb += b; worst = max(worst, err)
+            if f is not None and first is None:
+                first = f
+    return total, int(p.info.kernel_kind), nw, nb, worst, first, t_gpu, time.perf_counter() - t0, cores
