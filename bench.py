@@ -30,20 +30,33 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # harness: QD_TUNE / QD_JIT / QD_NO_FIXED ... are translated into qd_plan_options (quadrs_amd/engine.py)
 
 WORKLOADS = {
-    # name: fmt, samples per GPU, sample_rate, shift, (fc, decimate, taps), width, stride
+    # name: fmt, samples per GPU, sample_rate, shift, (fc, decimate, taps), width, stride; {size} = the slab's size per GPU
     "cfg3p": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=280000, lp=(200_000, 32, 200), W=128, S=128,
-                  desc="16 GiB cf32: shift 280000 -> 200-tap FIR (lowpass -power 100) decimate 32 -> sparkfft -width 128 (north_star target chain)"),
+                  desc="{size} cf32: shift 280000 -> 200-tap FIR (lowpass -power 100) decimate 32 -> sparkfft -width 128 (north_star target chain)"),
     "cfg2": dict(fmt=0, n=1 << 27, sr=21_000_000, shift=280000, lp=(2_000_000, 16, 40), W=128, S=128,
-                 desc="1 GiB cf32 @21Msps: shift 280000 -> lowpass -power 20 -decimate 16 2000000 -> sparkfft -width 128"),
+                 desc="{size} cf32 @21Msps: shift 280000 -> lowpass -power 20 -decimate 16 2000000 -> sparkfft -width 128"),
     "cfg3": dict(fmt=1, n=1 << 33, sr=21_000_000, shift=280000, lp=(200_000, 32, 400), W=64, S=16,
-                 desc="16 GiB cs8: unpack -> shift -> lowpass -power 200 -decimate 32 200000 -> sparkfft -width 64 -stride 16"),
+                 desc="{size} cs8: unpack -> shift -> lowpass -power 200 -decimate 32 200000 -> sparkfft -width 64 -stride 16"),
     "cfg4": dict(fmt=0, n=1 << 32, sr=100_000_000, shift=None, lp=(5_000_000, 8, 512), W=1024, S=1024,
-                 desc="gen 64 cosines @100 Msps, 32 GiB cf32: 512-tap FIR decimate 8 -> 1024-pt FFT"),
+                 desc="gen 64 cosines @100 Msps, {size} cf32: 512-tap FIR decimate 8 -> 1024-pt FFT"),
+    # BASELINE.json configs[4]: the cfg3 chain on a cf32 stream sharded over the node, 16 GiB per GPU (128 GiB at 8 GPUs)
+    "cfg5": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=280000, lp=(200_000, 32, 400), W=64, S=16,
+                 desc="{size} cf32 per GPU: shift 280000 -> lowpass -power 200 -decimate 32 200000 -> sparkfft -width 64 -stride 16 (configs[4])"),
 }
+
+
+def workload_desc(cfg):
+    size = cfg["n"] * BPS[cfg["fmt"]]
+    txt = f"{size / (1 << 30):g} GiB" if size >= (1 << 30) else f"{size / (1 << 20):g} MiB"
+    return cfg["desc"].format(size=txt)
+
+
 DEFAULT_WORKLOAD = "cfg3p"
 BPS = {0: 8, 1: 2, 2: 2, 3: 4}
+STREAM_SEED = 0x5EED0002     # ONE seed for the whole stream: the generator is keyed by absolute sample index, not by rank
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E data-sheet peak (MI355X_MICROARCH.md); ~6300 measured copy
 # VALU issue rates measured on MI355X at four waves per SIMD, chip unthrottled at 2.4 GHz (scripts/ubench_pk.hip,
 # profiles/r02/ubench_pk.log): ns per wave-instruction per SIMD.  A packed f32 op (two lane-operations) costs what an f64 op
@@ -77,28 +90,44 @@ def valu_roof_msamples(cfg, nco_order):
     return LANES_PER_CHIP / (ns_per_lane_sample * 1e-9) / 1e6, f32 + 2.0 * pk, f64
 
 
-def synth_slab(torch, fmt, first, count, seed, device):
-    """Deterministic synthetic IQ (tone at -shift + FSK-ish sign flips + noise + DC), generated on
-    the device in chunks so nothing large crosses PCIe."""
+def _splitmix64(torch, z):
+    """splitmix64 finaliser on an int64 tensor (two's-complement wrap-around is what the generator wants)."""
+    def lsr(v, k):                                   # logical shift right on int64
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    z = (z ^ lsr(z, 30)) * -4658895280553007687      # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * -7723592293110705685      # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def synth_slab(torch, fmt, first, count, seed, device, out=None):
+    """Deterministic synthetic IQ (tone at -shift + FSK-ish sign flips + noise + DC), generated on the device in chunks so
+    nothing large crosses PCIe.  COUNTER-BASED: every value is a pure function of (seed, absolute sample
+    index) — the noise is a splitmix64 hash of the index pushed through Box-Muller — so any rank of any world size
+    regenerates exactly the bytes of the one-rank stream, halo included.  `out`: write into this (uint8 view of the) slab
+    instead of allocating."""
     import numpy as np
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
     chunk = 1 << 24
-    if fmt == 0:
-        out = torch.empty(count, 2, dtype=torch.float32, device=device)
-    elif fmt == 3:
-        out = torch.empty(count, 2, dtype=torch.int16, device=device)
+    dt = {0: torch.float32, 3: torch.int16, 1: torch.int8, 2: torch.uint8}[fmt]
+    if out is None:
+        out = torch.empty(count, 2, dtype=dt, device=device)
     else:
-        out = torch.empty(count, 2, dtype=torch.uint8 if fmt == 2 else torch.int8, device=device)
+        out = out.view(dt).reshape(-1, 2)
+        assert out.shape[0] == count
+    gold = -7046029254386353131                      # 0x9E3779B97F4A7C15
     for a in range(0, count, chunk):
         b = min(count, a + chunk)
-        n = torch.arange(first + a, first + b, device=device, dtype=torch.float64)
+        idx = torch.arange(first + a, first + b, device=device, dtype=torch.int64)
+        n = idx.to(torch.float64)
         ph = (n * (-280000.0 / 21e6)) % 1.0 * (2 * np.pi)
         sign = torch.sign(torch.sin(n * (2 * np.pi * 9600.0 / 21e6)) + 1e-9)
         re = (0.02 * torch.cos(ph) * sign).float()
         im = (0.02 * torch.sin(ph) * sign).float()
-        noise = torch.randn(b - a, 2, generator=g, device=device, dtype=torch.float32) * 0.002
-        x = torch.stack([re + 0.005, im - 0.024], dim=1) + noise
+        h = _splitmix64(torch, (idx + int(seed)) * gold)
+        u1 = (((h >> 40) & 0xFFFFFF).to(torch.float64) + 0.5) * (1.0 / 16777216.0)        # (0, 1): 24 bits each
+        u2 = (((h >> 8) & 0xFFFFFF).to(torch.float64) + 0.5) * (1.0 / 16777216.0)
+        r = torch.sqrt(-2.0 * torch.log(u1)) * 0.002
+        th = u2 * (2 * np.pi)
+        x = torch.stack([re + 0.005 + (r * torch.cos(th)).float(), im - 0.024 + (r * torch.sin(th)).float()], dim=1)
         if fmt == 0:
             out[a:b] = x
         elif fmt == 1:
@@ -110,56 +139,88 @@ def synth_slab(torch, fmt, first, count, seed, device):
     return out
 
 
-def sample_power(step, torch, seconds):
+class GpuSensors:
+    """Board power / shader clock of ONE GPU, read from the amdgpu hwmon files in sysfs (power1_average or power1_input in
+    microwatts, freq1_input in Hz, power1_cap in microwatts).  Plain file reads: the process that holds the GPU never forks or
+    execs anything to learn its own power (rocm-smi is a Python script; starting it from a process that has initialised HIP is
+    an exec-after-GPU-init, which this pool refuses — VERDICT r02 item 9)."""
+
+    def __init__(self, pci_bdf=None):
+        import glob
+        self.power = self.freq = self.cap = None
+        cands = []
+        if pci_bdf:
+            cands = glob.glob(f"/sys/bus/pci/devices/{pci_bdf}/hwmon/hwmon*")
+        if not cands and pci_bdf is None:
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        for d in cands:
+            for f in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(d, f)):
+                    self.power = os.path.join(d, f)
+                    break
+            if self.power:
+                self.freq = os.path.join(d, "freq1_input") if os.path.exists(os.path.join(d, "freq1_input")) else None
+                self.cap = os.path.join(d, "power1_cap") if os.path.exists(os.path.join(d, "power1_cap")) else None
+                self.dir = d
+                break
+
+    @staticmethod
+    def for_torch_device(torch, index=0):
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            bdf = None
+        s = GpuSensors(bdf)
+        s.bdf = bdf
+        return s
+
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except Exception:
+            return None
+
+    def ok(self):
+        return self.power is not None and self._num(self.power) is not None
+
+    def read(self):
+        """(watts, sclk MHz or None)"""
+        w = self._num(self.power) if self.power else None
+        f = self._num(self.freq) if self.freq else None
+        return (w * 1e-6 if w is not None else None, f * 1e-6 if f is not None else None)
+
+    def cap_watts(self):
+        c = self._num(self.cap) if self.cap else None
+        return c * 1e-6 if c is not None else None
+
+
+def sample_power(step, torch, seconds, sensors=None):
     """AFTER the timed region: keep the kernel running back to back for a few seconds and read the board's package power and
-    shader clock from rocm-smi meanwhile (informational: says whether the kernel runs at the power cap — DESIGN.md section 7).
-    Returns None where rocm-smi is missing or prints something else."""
-    import re
-    import subprocess
-    import threading
+    shader clock meanwhile (informational: says whether the kernel runs at the power cap — DESIGN.md section 7).  The readings
+    come from sysfs (GpuSensors), in this process, between batches of launches.  Returns None where the files are missing."""
+    sensors = sensors or GpuSensors.for_torch_device(torch, torch.cuda.current_device())
+    if not sensors.ok():
+        return None
     samples = []
-    stop = threading.Event()
-    # which rocm-smi card is torch's device 0?  match the PCI bus id; fall back to the first card listed
-    card = None
-    try:
-        pr = torch.cuda.get_device_properties(0)
-        want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        bus = subprocess.run(["rocm-smi", "--showbus"], capture_output=True, text=True, timeout=10).stdout
-        for mm in re.finditer(r"GPU\[(\d+)\]\s*:\s*PCI Bus:\s*([0-9A-Fa-f:.]+)", bus):
-            if mm.group(2).lower().startswith(want):
-                card = mm.group(1)
-    except Exception:
-        card = None
-    pre = r"GPU\[%s\]\s*:\s*" % card if card is not None else ""
-
-    def poll():
-        while not stop.is_set():
-            try:
-                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
-            except Exception:
-                return
-            w = re.search(pre + r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", txt)
-            c = re.search(pre + r"sclk clock level:.*?\((\d+)Mhz\)", txt)
-            m = re.search(pre + r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
-            if w and c:
-                samples.append((float(w.group(1)), int(c.group(1)), float(m.group(1)) if m else None))
-            stop.wait(0.3)
-
-    th = threading.Thread(target=poll, daemon=True)
     t_end = time.perf_counter() + seconds
-    th.start()
     while time.perf_counter() < t_end:
         for _ in range(16):
             step()
+        w, mhz = sensors.read()            # read while the queue is still full of launches, then drain
         torch.cuda.synchronize()
-    stop.set()
-    th.join(timeout=15)
-    samples = samples[1:] if len(samples) > 2 else samples          # the first reading may predate the load
+        if w is not None:
+            samples.append((w, mhz))
+    samples = samples[2:] if len(samples) > 4 else samples          # the first readings may predate the load
     if not samples:
         return None
-    return {"watts": max(s[0] for s in samples), "sclk_mhz": min(s[1] for s in samples), "cap_watts": samples[-1][2], "samples": len(samples),
-            "card": card if card is not None else "first listed",
-            "note": "rocm-smi while the kernel runs back to back, after the timed region: highest package power, lowest shader clock seen"}
+    clocks = [s[1] for s in samples if s[1]]
+    return {"watts": max(s[0] for s in samples), "watts_mean": sum(s[0] for s in samples) / len(samples),
+            "sclk_mhz": min(clocks) if clocks else None, "sclk_mhz_mean": sum(clocks) / len(clocks) if clocks else None,
+            "cap_watts": sensors.cap_watts(), "samples": len(samples), "card": getattr(sensors, "bdf", None),
+            "note": "amdgpu hwmon (sysfs) while the kernel runs back to back, after the timed region: highest package power, lowest shader clock seen"}
 
 
 def cpu_baseline(cfg, slab_bytes, target_s=12.0):
@@ -272,30 +333,72 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
     shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, info.tile_windows)
     me = shards[rank]
 
-    if name == "cfg4":
-        # configs[3]: `gen` with 64 cosines @100 Msps (f_k = (k-32)*1 562 500 + 390 625 Hz), generated on
-        # the device by the engine's own Gen kernel, outside the timed region
-        own = torch.empty(me.own_count, 2, dtype=torch.float32, device=device)
-        tones = [(k - 32) * 1_562_500 + 390_625 for k in range(64)]
-        piece = 1 << 28
-        for a in range(0, me.own_count, piece):
-            Q.gen_device(tones, cfg["sr"], me.own_first + a, own[a:a + piece])
-        torch.cuda.synchronize()
-    else:
-        own = synth_slab(torch, fmt, me.own_first, me.own_count, 0x5EED0002 + rank, device)
-    own_u8 = own.view(torch.uint8).reshape(-1)
-    if world == 1:
-        slab = own_u8
-    elif args.rehearse:
-        slab = SH.exchange(own_u8.cpu(), shards, rank, bps, dist).to(device)         # gloo: staged through the host
-    else:
-        slab = SH.exchange(own_u8, shards, rank, bps, dist)                          # halo over RCCL/xGMI, once
-    del own, own_u8
+    # ONE pre-sized buffer per rank: own samples first, room for the halo behind them; the generator writes into it and the
+    # halo is received into its tail (no second slab, no concatenation)
+    slab = SH.alloc_slab(me, bps, device, torch)
+    own_b = me.own_count * bps
+
+    def generate(first, count, dst_u8):
+        """samples [first, first + count) of the stream into dst_u8 (device, uint8): pure function of the absolute index"""
+        if count == 0:
+            return
+        if name == "cfg4":
+            # configs[3]: `gen` with 64 cosines @100 Msps (SURVEY 8(d): f_k = (k-32)*1 562 500 + 390 625 Hz), generated on
+            # the device by the engine's own Gen kernel, outside the timed region
+            tones = [(k - 32) * 1_562_500 + 390_625 for k in range(64)]
+            dst = dst_u8.view(torch.float32).reshape(-1, 2)
+            piece = 1 << 28
+            for a in range(0, count, piece):
+                Q.gen_device(tones, cfg["sr"], first + a, dst[a:a + piece])
+            torch.cuda.synchronize()
+        else:
+            synth_slab(torch, fmt, first, count, STREAM_SEED, device, out=dst_u8)
+
+    generate(me.own_first, me.own_count, slab[:own_b])
+    if world > 1:
+        if args.rehearse:
+            host = slab.cpu()
+            SH.exchange(host, shards, rank, bps, dist)                                # gloo: staged through the host
+            slab[own_b:] = host[own_b:].to(device)
+            del host
+        else:
+            SH.exchange(slab, shards, rank, bps, dist)                                # halo over RCCL/xGMI, once, in place
     nw = me.w1 - me.w0
     out = torch.empty(nw, cfg["W"], dtype=torch.float32, device=device)
 
     def step():
         plan.run_device(slab, out, me.w0, nw, src_first=me.need_first, src_count=me.need_count)
+
+    # ---- seam verification (multi-rank runs; outside the timed region).  (1) The halo this rank RECEIVED is compared, byte for
+    # byte, with the same samples regenerated locally (the generator is keyed by absolute index).  (2) The rank's first and last
+    # four windows — the last ones read the halo — are recomputed by a FRESH plan from a small slab generated from scratch, and
+    # compared with the rows of the sharded run.  Every rank's verdict is AND-reduced into "seams_verified".
+    seams = None
+    if world > 1:
+        ok = True
+        if me.halo:
+            regen = torch.empty(me.halo * bps, dtype=torch.uint8, device=device)
+            generate(me.own_first + me.own_count, me.halo, regen)
+            ok = ok and bool(torch.equal(regen, slab[own_b:]))
+            del regen
+        step()
+        torch.cuda.synchronize()
+        if nw:
+            chk = Q.Plan(fmt, cfg["sr"], n_total, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
+            k = int(min(4, nw))
+            for w_first in sorted({me.w0, me.w1 - k}):
+                first, count = chk.src_range(w_first, k)
+                small = torch.empty(count * bps, dtype=torch.uint8, device=device)
+                generate(first, count, small)
+                rows = torch.empty(k, cfg["W"], dtype=torch.float32, device=device)
+                chk.run_device(small, rows, w_first, k, src_first=first, src_count=count)
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.equal(rows.view(torch.int32), out[w_first - me.w0:w_first - me.w0 + k].view(torch.int32)))
+                del small, rows
+            chk.close()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if args.rehearse else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        seams = bool(flag.item())
 
     # settle: the first launches of a process run at ramping clocks; untimed, before the W warmup steps of the contract
     t_settle = time.perf_counter()
@@ -380,7 +483,7 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
         if power:
             roof["power"] = power
         res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
-               "outputs_finite": finite, "kernel_kind": int(info.kernel_kind), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
+               "outputs_finite": finite, "seams_verified": seams, "kernel_kind": int(info.kernel_kind), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
         if with_cpu:
             nwin_cpu = int(min(nw, max(64, (1 << 30) // (info.raw_step * bps))))     # at most 1 GiB of the stream goes to the host
             first, count = plan.src_range(me.w0 + (nw - nwin_cpu) // 2, nwin_cpu)
@@ -523,14 +626,21 @@ def main():
                        with_cpu=(world == 1 and not args.no_cpu_baseline))
     args.power_sample = False
     others = None
-    if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
-        # the other BASELINE configs, briefly (same protocol, fewer steps, no CPU leg): parity-test cases first, bench lines second
+    if args.workload == DEFAULT_WORKLOAD and not args.no_others and (world > 1 or args.samples_log2 is None):
+        # the other BASELINE configs, briefly (same protocol, fewer steps, no CPU leg): parity-test cases first, bench lines second.
+        # One GPU: configs[1..3]; several GPUs: configs[4] (the cfg3 chain on a cf32 stream sharded over the ranks).
         others = {}
-        for name in ("cfg2", "cfg3", "cfg4"):
-            r = measure(args, name, dict(WORKLOADS[name]), rank, world, device, dist, 8, 2, with_cpu=False)
+        for name in (("cfg2", "cfg3", "cfg4") if world == 1 else ("cfg5",)):
+            ocfg = dict(WORKLOADS[name])
+            if args.samples_log2 is not None:
+                ocfg["n"] = 1 << args.samples_log2
+            r = measure(args, name, ocfg, rank, world, device, dist, 8, 2, with_cpu=False)
+            if rank != 0:
+                continue
             others[name] = {"value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"], "steps": 8, "warmup": 2,
                             "bound": r["roofline"]["bound"], "hbm_frac": r["roofline"]["hbm"]["frac"], "valu_frac": r["roofline"]["valu"]["frac"],
-                            "kernel_ms": r["roofline"]["kernel_ms"], "config": WORKLOADS[name]["desc"]}
+                            "kernel_ms": r["roofline"]["kernel_ms"], "config": workload_desc(ocfg),
+                            **({"seams_verified": r["seams_verified"]} if r.get("seams_verified") is not None else {})}
     if rank == 0:
         line = {
             "metric": "Msamples/s through shift->FIR->FFT chain",
@@ -540,13 +650,15 @@ def main():
             "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg['desc']}", "samples_per_gpu": cfg["n"], "taps": cfg["lp"][2],
+            "config": {"workload": f"{args.workload}: {workload_desc(cfg)}", "samples_per_gpu": cfg["n"], "taps": cfg["lp"][2],
                        "decimate": cfg["lp"][1], "width": cfg["W"], "stride": cfg["S"],
                        "parallelism": f"window-range shards x{world}, halo {(cfg['W'] - cfg['S']) * cfg['lp'][1] + cfg['lp'][2]} samples",
                        "outputs_finite": main_res["outputs_finite"], "kernel_kind": main_res["kernel_kind"],
                        "tile_windows": main_res["tile_windows"], "threads": main_res["threads"]},
             "roofline": main_res["roofline"],
         }
+        if main_res.get("seams_verified") is not None:
+            line["seams_verified"] = main_res["seams_verified"]     # multi-rank: halo bytes + first / last windows of every rank re-derived locally
         for k in ("cpu_baseline", "cpu_allcores"):
             if k in main_res:
                 line[k] = main_res[k]

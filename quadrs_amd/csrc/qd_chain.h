@@ -139,7 +139,9 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
 }
 
 constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32,
-                   kGeoDeferFft = 64, kGeoPackedTile = 128;   // FixedGeo FLAGS_ bits
+                   kGeoDeferFft = 64, kGeoPackedTile = 128, kGeoNtLoads = 256;   // FixedGeo FLAGS_ bits
+// cache policy (buffer-load aux operand) of the phase-1 stream loads: bit 8 -> nt, bits 11 / 12 -> sc0 / sc1
+constexpr int ct_load_aux(uint32_t flags) { return ((flags & 256u) ? 2 : 0) | ((flags & 2048u) ? 1 : 0) | ((flags & 4096u) ? 16 : 0); }
 typedef float v2f __attribute__((ext_vector_type(2)));      // operand type of the v_pk_*_f32 instructions
 
 template <uint32_t W_, uint32_t S_, uint32_t D_, uint32_t T_, uint32_t G_, uint32_t FIRB_ = 8, uint32_t FIRR_ = 1, uint32_t PAD_ = 1, uint32_t BATCH_ = 1,
@@ -165,7 +167,12 @@ struct FixedGeo {
     static constexpr uint32_t kFirBlock = FIRB_;   // taps per software-pipelined FIR block (register budget knob)
     // outputs per lane in the FIR (register tiling): each LDS sample read feeds FIRR_ accumulators.
     // Needs 8-aligned geometry; falls back to 1 otherwise.
-    static constexpr uint32_t kFirTile = (FIRR_ > 1 && D_ % 8 == 0 && ((T_ - T_ / 2) % D_) % 8 == 0 && T_ % 8 == 0 && (T_ / 2) % 8 == 0 &&
+    // The straight-line packed two-output form (fir_tiled2_pk, FLAGS_ bit 7) walks 4-sample blocks with compile-time offsets
+    // and needs 4-aligned geometry only (T = 200: c = 100, T/2 = 100).
+    static constexpr bool kFirTile4 = FIRR_ == 2 && (FLAGS_ & kGeoPackedTile) && PAD_ == 2 && D_ % 4 == 0 && (T_ - T_ / 2) % 4 == 0 && T_ % 4 == 0 &&
+                                      (T_ / 2) % 4 == 0 && W_ % 2 == 0 && S_ % 2 == 0 && ct_pow2(D_) && D_ / 4 <= 8 && T_ > D_ + 16 && !(T_ > 0 && S_ < W_);
+    static constexpr uint32_t kFirTile = kFirTile4 ? 2u :
+                                         (FIRR_ > 1 && D_ % 8 == 0 && ((T_ - T_ / 2) % D_) % 8 == 0 && T_ % 8 == 0 && (T_ / 2) % 8 == 0 &&
                                           W_ % FIRR_ == 0 && S_ % FIRR_ == 0 && ct_pow2(D_) && ct_pow2(FIRR_) &&
                                           T_ > (FIRR_ - 1) * D_ + 8) ? FIRR_ : 1;      // at least three interior 4-sample blocks
     // LDS pad period: one pad element per PD samples.  PD = D for the lane-per-output FIR (lane stride D + 1:
@@ -1013,7 +1020,11 @@ template <class GeoT, int TURN>
 __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *h, float2 *full, const uint32_t *jm, float2 *snap) {
     constexpr uint32_t D = GeoT::D, T = GeoT::T, c = GeoT::c;
     constexpr uint32_t L = D + T, NB = L / 4, HB = T / 4, LAG = D / 4;      // sample blocks, tap blocks, output 1's lag in blocks
-    constexpr int PF = 3, NS = PF + (int)LAG + 1;                            // sample / tap blocks in flight, live tap slots
+    // Output 1 uses the tap block output 0 used LAG blocks earlier.  Short lags (D <= 16) keep those blocks live in registers;
+    // longer ones (D = 32: 8 blocks = 32 VGPRs) read the block a second time instead — a broadcast ds_read_b128, one LDS
+    // bank row — so the FIR fits a 128-VGPR kernel beside the phase-1 prefetch registers.
+    constexpr bool kReTap = LAG > 4;
+    constexpr int PF = 3, NS = kReTap ? PF : PF + (int)LAG + 1;              // sample / tap blocks in flight, live tap slots
 
     static_assert(GeoT::kFirTile == 2 && GeoT::PD == 2 * D && GeoT::pshift != 0xffffffffu && GeoT::kPad == 2, "two-output packed FIR: layout");
     static_assert(D % 4 == 0 && T % 4 == 0 && c % 4 == 0 && (T / 2) % 4 == 0 && NB > (uint32_t)PF && LAG >= 1 && LAG <= 8, "two-output packed FIR: geometry");
@@ -1022,7 +1033,7 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
     // copied when the chain reaches the lane's jmax.  Only the wave that owns such outputs takes the (wave-uniform) branches.
     const bool need_snap = __builtin_amdgcn_ballot_w64(jm[0] < T || jm[1] < T) != 0;
     auto cand = [&](uint32_t j) -> bool { return j >= T / 2 + D && j < T && ((j - T / 2) % D) == 0; };
-    float4 xa[PF], xb[PF], hh[NS];
+    float4 xa[PF], xb[PF], hh[NS], gg[kReTap ? PF : 1];
     // LDS address of the taps, kept in ONE vector register: every tap read is base + immediate (left uniform, hipcc forms one
     // scalar address per block — 128 scalars, spilled to vector lanes — and moves each into a vector register for its read)
     typedef float f4n __attribute__((ext_vector_type(4)));
@@ -1039,6 +1050,7 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
         xa[b % PF] = *reinterpret_cast<const float4 *>(pp);
         xb[b % PF] = *reinterpret_cast<const float4 *>(pp + 2);
         if (b < HB) { const f4n q = hl[b]; hh[b % NS] = make_float4(q.x, q.y, q.z, q.w); }
+        if constexpr (kReTap) { if (b >= LAG) { const f4n q = hl[b - LAG]; gg[b % PF] = make_float4(q.x, q.y, q.z, q.w); } }
     };
 #pragma unroll
     for (int b = 0; b < PF; ++b) load(b);
@@ -1067,7 +1079,7 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
         }
 #endif
         if (b >= LAG && b < HB) {                                            // both outputs take this block
-            const float4 H = hh[b % NS], G = hh[(b - LAG) % NS];
+            const float4 H = hh[b % NS], G = kReTap ? gg[b % PF] : hh[(b - LAG) % NS];
             const v2f h01 = {H.x, H.y}, h23 = {H.z, H.w}, g01 = {G.x, G.y}, g23 = {G.z, G.w};
             asm volatile("v_pk_mul_f32 %2, %6, %10 op_sel_hi:[1,0]\n\t"
                          "v_pk_mul_f32 %3, %6, %12 op_sel_hi:[1,0]\n\t"
@@ -1088,7 +1100,7 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
                          : "+v"(a0), "+v"(a1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
                          : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23), "v"(g01), "v"(g23));
         } else {                                                             // the first LAG blocks: output 0 only; the last LAG: output 1 only
-            const float4 H = hh[(b < HB ? b : b - LAG) % NS];
+            const float4 H = b < HB ? hh[b % NS] : (kReTap ? gg[b % PF] : hh[(b - LAG) % NS]);
             const v2f h01 = {H.x, H.y}, h23 = {H.z, H.w};
             v2f &acc = b < HB ? a0 : a1;
             asm volatile("v_pk_mul_f32 %1, %3, %7 op_sel_hi:[1,0]\n\t"
@@ -1152,6 +1164,95 @@ __device__ __forceinline__ float2 fir_prefix(const float2 *raw, uint32_t t0, uin
         __builtin_amdgcn_sched_barrier(0);
     }
     return make_float2(ar, ai);
+}
+
+// One wave transforms a parked tile (pg windows at fbp, FIR output in rustfft's digit-reversed order) and writes its output:
+// LDS operations of one wave execute in order, so the passes are separated by a compiler-level fence only.  twl = the layer
+// twiddles (LDS or global), pw0 = the tile's first window.
+template <class GeoT>
+__device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const GeoT &geo, const float2 *twl, float2 *fbp, uint64_t pw0, uint32_t pg, uint32_t tid) {
+    uint32_t lane = tid & 63u;
+    asm volatile("" : "+v"(lane));            // opaque: per-lane LDS / output addresses are rebuilt per tile, not hoisted out of the tile loop and spilled
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    const uint32_t base = geo.base_len, log_tpw = geo.logW - geo.log_base;
+    const uint32_t n_task = pg << log_tpw;
+    for (uint32_t t = lane; t < n_task; t += 64) {
+        float2 *d = fbp + (size_t)t * base;
+        if (base == 16) {
+            float2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = d[i];
+            bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = v[i];
+        } else if (base == 8) {
+            float2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = d[i];
+            bf8(v, P.root2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = v[i];
+        } else if (base == 4) {
+            float2 v0 = d[0], v1 = d[1], v2 = d[2], v3 = d[3];
+            bf4(v0, v1, v2, v3);
+            d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+        } else if (base == 2) {
+            float2 v0 = d[0], v1 = d[1];
+            bf2(v0, v1);
+            d[0] = v0; d[1] = v1;
+        }
+    }
+    uint32_t cols = base, log_cols = geo.log_base;
+    const float2 *tw = twl;
+    for (uint32_t layer = 0; layer < geo.layers; ++layer) {
+        wsync();
+        const uint32_t n_bf = (pg << geo.logW) >> 2;
+        for (uint32_t t = lane; t < n_bf; t += 64) {
+            const uint32_t chunk = t >> log_cols, i = t & (cols - 1);
+            float2 *d = fbp + (size_t)chunk * 4 * cols + i;
+            float2 s0 = d[0];
+            float2 s1 = cmul(d[cols], tw[3 * i]);
+            float2 s2 = cmul(d[2 * cols], tw[3 * i + 1]);
+            float2 s3 = cmul(d[3 * cols], tw[3 * i + 2]);
+            bf4(s0, s1, s2, s3);
+            d[0] = s0; d[cols] = s1; d[2 * cols] = s2; d[3 * cols] = s3;
+        }
+        tw += 3 * cols;
+        cols *= 4;
+        log_cols += 2;
+    }
+    wsync();
+    const uint64_t wrel = pw0 - P.out_window0;
+    const uint32_t n_out_s = pg << geo.logW;
+    if (P.epi == 2) {
+        // freq_levels: the norms replace the transformed samples in place (every lane reads its share first), then one lane
+        // per window forms the two sequential half sums (src/fft.rs:95-97)
+        constexpr uint32_t K = GeoT::kFixed ? (GeoT::G_ct * GeoT::W_ct + 63) / 64 : 1;
+        float nm[K];
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; nm[k] = o < n_out_s ? norm_ref(fbp[o]) : 0.f; }
+        wsync();
+        float *nb = reinterpret_cast<float *>(fbp);
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; if (o < n_out_s) nb[o] = nm[k]; }
+        wsync();
+        if (lane < pg) {
+            const float *q = nb + (lane << geo.logW);
+            float first = 0.f, second = 0.f;
+            for (uint32_t k = 0; k < geo.W / 2; ++k) first = first + q[k];
+            for (uint32_t k = geo.W / 2; k < geo.W; ++k) second = second + q[k];
+            reinterpret_cast<uint8_t *>(P.out)[wrel + lane] = first < second ? 0 : 1;
+        }
+    } else {
+        float *outf = reinterpret_cast<float *>(P.out) + (wrel << geo.logW);
+        uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << geo.logW);
+        for (uint32_t o = lane; o < n_out_s; o += 64) {
+            const float2 xv = fbp[o ^ (geo.W >> 1)];
+            const float nm = norm_ref(xv);
+            if (P.epi == 0) outf[o] = nm;
+            else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
+        }
+    }
 }
 
 // deferred FFT (see k_chain)
@@ -1285,9 +1386,15 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     const bool dyn = P.work != nullptr && xcd_walk;
     const uint32_t my_x = blockIdx.x & 7u;
     auto claim_resolve = [&](unsigned long long got) -> uint64_t {        // one lane; `got` = reply of the add on the own counter
-        if (got < xcd_limit(my_x)) return (uint64_t)my_x * n8 + got;
+        // The group index is made opaque here: left visible, hipcc unrolls the help-the-others loop, hoists its seven limits,
+        // bases and counter addresses out of the TILE loop and spills them (56 of the kernel's SGPR spills, each read back with
+        // a v_readlane on the FIR wave between its last tap and the barrier the whole workgroup waits at).
+        uint32_t mx = my_x;
+        asm volatile("" : "+s"(mx));
+        if (got < xcd_limit(mx)) return (uint64_t)mx * n8 + got;
+#pragma unroll 1
         for (uint32_t k = 1; k < 8; ++k) {                                // own eighth exhausted: help the others
-            const uint32_t xx = (my_x + k) & 7u;
+            const uint32_t xx = (mx + k) & 7u;
             const uint64_t lim = xcd_limit(xx);
             if (lim == 0) continue;
             const unsigned long long i = atomicAdd(&P.work[16 * xx], 1ull);
@@ -1327,90 +1434,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     bool dprev_valid = false;
     // One wave transforms the parked tile and writes its output: LDS operations of one wave execute in order, so the passes
     // are separated by a compiler-level fence only.
-    auto wave_fft_epilogue = [&](float2 *fbp, uint64_t pw0, uint32_t pg) {
-        uint32_t lane = tid & 63u;
-        asm volatile("" : "+v"(lane));            // opaque: per-lane LDS / output addresses are rebuilt per tile, not hoisted out of the tile loop and spilled
-        auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-        const uint32_t base = geo.base_len, log_tpw = geo.logW - geo.log_base;
-        const uint32_t n_task = pg << log_tpw;
-        for (uint32_t t = lane; t < n_task; t += 64) {
-            float2 *d = fbp + (size_t)t * base;
-            if (base == 16) {
-                float2 v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = d[i];
-                bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) d[i] = v[i];
-            } else if (base == 8) {
-                float2 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = d[i];
-                bf8(v, P.root2);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) d[i] = v[i];
-            } else if (base == 4) {
-                float2 v0 = d[0], v1 = d[1], v2 = d[2], v3 = d[3];
-                bf4(v0, v1, v2, v3);
-                d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
-            } else if (base == 2) {
-                float2 v0 = d[0], v1 = d[1];
-                bf2(v0, v1);
-                d[0] = v0; d[1] = v1;
-            }
-        }
-        uint32_t cols = base, log_cols = geo.log_base;
-        const float2 *tw = twl;
-        for (uint32_t layer = 0; layer < geo.layers; ++layer) {
-            wsync();
-            const uint32_t n_bf = (pg << geo.logW) >> 2;
-            for (uint32_t t = lane; t < n_bf; t += 64) {
-                const uint32_t chunk = t >> log_cols, i = t & (cols - 1);
-                float2 *d = fbp + (size_t)chunk * 4 * cols + i;
-                float2 s0 = d[0];
-                float2 s1 = cmul(d[cols], tw[3 * i]);
-                float2 s2 = cmul(d[2 * cols], tw[3 * i + 1]);
-                float2 s3 = cmul(d[3 * cols], tw[3 * i + 2]);
-                bf4(s0, s1, s2, s3);
-                d[0] = s0; d[cols] = s1; d[2 * cols] = s2; d[3 * cols] = s3;
-            }
-            tw += 3 * cols;
-            cols *= 4;
-            log_cols += 2;
-        }
-        wsync();
-        const uint64_t wrel = pw0 - P.out_window0;
-        const uint32_t n_out_s = pg << geo.logW;
-        if (P.epi == 2) {
-            // freq_levels: the norms replace the transformed samples in place (every lane reads its share first), then one lane
-            // per window forms the two sequential half sums (src/fft.rs:95-97)
-            constexpr uint32_t K = GeoT::kFixed ? (GeoT::G_ct * GeoT::W_ct + 63) / 64 : 1;
-            float nm[K];
-#pragma unroll
-            for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; nm[k] = o < n_out_s ? norm_ref(fbp[o]) : 0.f; }
-            wsync();
-            float *nb = reinterpret_cast<float *>(fbp);
-#pragma unroll
-            for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; if (o < n_out_s) nb[o] = nm[k]; }
-            wsync();
-            if (lane < pg) {
-                const float *q = nb + (lane << geo.logW);
-                float first = 0.f, second = 0.f;
-                for (uint32_t k = 0; k < geo.W / 2; ++k) first = first + q[k];
-                for (uint32_t k = geo.W / 2; k < geo.W; ++k) second = second + q[k];
-                reinterpret_cast<uint8_t *>(P.out)[wrel + lane] = first < second ? 0 : 1;
-            }
-        } else {
-            float *outf = reinterpret_cast<float *>(P.out) + (wrel << geo.logW);
-            uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << geo.logW);
-            for (uint32_t o = lane; o < n_out_s; o += 64) {
-                const float2 xv = fbp[o ^ (geo.W >> 1)];
-                const float nm = norm_ref(xv);
-                if (P.epi == 0) outf[o] = nm;
-                else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
-            }
-        }
-    };
+    auto wave_fft_epilogue = [&](float2 *fbp, uint64_t pw0, uint32_t pg) { wave_fft_epilogue_fn<GeoT>(P, geo, twl, fbp, pw0, pg, tid); };
     // The same on FOUR waves, for one long window (W >= 256): Radix4's last layer combines four contiguous sub-transforms of W/4
     // points, and everything below it stays inside one sub-transform — so wave v transforms quarter v on its own (no workgroup
     // barrier, the FIR waves run on), the four meet ONCE at an arrival counter in LDS, and each then takes a quarter of the last
@@ -1552,10 +1576,10 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 uint32_t voff = tid * VECB;
                 if (i + 1 == RCH && kRem != NT * SPL) voff = voff < kLastVec ? voff : kLastVec;
                 if constexpr (sizeof(Vec) == 16) {
-                    const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), 0);
+                    const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), ct_load_aux(GeoT::kFlags));
                     pf[i].x = w.x; pf[i].y = w.y; pf[i].z = w.z; pf[i].w = w.w;
                 } else {
-                    const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), 0);
+                    const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), ct_load_aux(GeoT::kFlags));
                     pf[i].x = w.x; pf[i].y = w.y;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -2066,6 +2090,317 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         w[0] = wg_t0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = xcc & 0xf; w[3] = 1;
     }
 #endif
+    if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
+}
+
+// ---------------------------------------------------------------- the role-split kernel (FixedGeo FLAGS_ bit 9)
+//
+// k_chain keeps a tile's phases in sequence on ALL waves of the workgroup: phase 1 (4 waves), barrier, FIR (2 waves), barrier,
+// with the FFT of the previous tile on a third wave — a chain of ~11 000 cycles per 128-point window on the north_star shape,
+// during which the vector units are 76 % busy (profiles/r02/cfg3p_summary.json).  The chain, not HBM, sets the rate there: the
+// same launch shape streams 17 % faster with the arithmetic ablated.
+//
+// Here the roles are split across waves and run CONCURRENTLY on one tile buffer: four producer waves (unpack -> NCO -> LDS,
+// with the next tile's rows prefetched in registers, exactly k_chain's row-aligned phase 1) and one consumer wave (FIR of the
+// window's two halves, then FFT + |X| + store), 320 threads per workgroup, five waves per SIMD.  A window's outputs split in
+// two halves of W/2; half 0 reads tile rows [0, RA], half 1 rows [RB, RCH) (RB <= RA + 1), so one step of the consumer always
+// leaves a set of rows nobody reads, and the producers refill exactly those:
+//     step 1   consumer: FIR of half 0 (rows 0 .. RA)         producers: rows RA+1 .. RCH-1 of THIS window
+//     step 2   consumer: FIR of half 1 (rows RB .. RCH-1)     producers: rows 0 .. RB-1 of the NEXT window
+//     step 3   consumer: FFT + epilogue (no raw rows)         producers: rows RB .. RA of the next window
+// One s_barrier ends each step (every wave executes the same number of barriers: no flags, no polling, nothing to deadlock).
+// The products, their order and every rounding are k_chain's: the same process_row, fir_pair and wave_fft_epilogue_fn.
+constexpr uint32_t kGeoPipe = 512, kGeoPipeFftWave = 1024;
+constexpr uint32_t kGeoLoadSc0 = 2048, kGeoLoadSc1 = 4096;   // development: cache-policy bits of the phase-1 stream loads (with kGeoNtLoads)
+      // bit 10: a sixth wave takes the FFT + epilogue (384 threads, two FFT slots)
+constexpr int kPipeThreads = 320;
+template <int V> struct IntC { static constexpr int value = V; };
+
+template <int FMT, class GeoT>
+constexpr bool pipe_geometry_ok(int rch) {
+    if constexpr (!GeoT::kFixed) return false;
+    else {
+        constexpr uint32_t ROW = 256u * FmtTraits<FMT>::SPL;
+        constexpr uint32_t tile_raw = GeoT::W * GeoT::D + GeoT::T;
+        return GeoT::G == 1 && GeoT::S == GeoT::W && GeoT::kPairFir && GeoT::W == 128 && (GeoT::S * GeoT::D) % ROW == 0 &&
+               (uint32_t)rch == (tile_raw + ROW - 1) / ROW && GeoT::D % FmtTraits<FMT>::SPL == 0 && GeoT::T > GeoT::D;
+    }
+}
+
+template <int FMT, int NCO, class GeoT, int RCH, int LB, int NT = kPipeThreads>
+__global__ __launch_bounds__(NT, LB) void k_chain_pipe(const ChainParams P) {
+    static_assert(NT == 320 || NT == 384, "four producer waves + the FIR wave (+ an FFT wave)");
+    constexpr bool kFftWave = NT == 384;          // a sixth wave transforms the PREVIOUS window while the FIR wave filters this one (two FFT slots)
+    using FT = FmtTraits<FMT>;
+    using Vec = typename FT::Vec;
+    constexpr int SPL = FT::SPL;
+    constexpr bool HAS_SHIFT = NCO != 0;
+    static_assert(pipe_geometry_ok<FMT, GeoT>(RCH), "role-split kernel: non-overlapping 128-point windows on a row-aligned, 16-byte-row tile");
+    constexpr uint32_t PT = 256;                                                   // producer threads
+    constexpr uint32_t W = GeoT::W, D = GeoT::D, T = GeoT::T, Dp = GeoT::Dp, HO = W / 2;
+    constexpr uint32_t ROW = PT * SPL, ROWB = ROW * FT::BPS, VECB = SPL * FT::BPS;
+    constexpr uint32_t kTileRaw = W * D + T, kRem = kTileRaw - (RCH - 1) * ROW;
+    constexpr int RA = (int)((GeoT::c + (HO - 1) * D + T - 1) / ROW);              // last row half 0 reads
+    constexpr int RB = (int)((HO * D + GeoT::c) / ROW);                            // first row half 1 reads
+    static_assert(RB <= RA + 1 && RA < RCH && RB >= 1, "half split");
+    const GeoT geo(P);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *raw = reinterpret_cast<float2 *>(smem);                                // same layout as k_chain (host: lds_for)
+    float2 *fb0 = raw + geo.lds_raw_elems;
+    float2 *twl = fb0 + (size_t)GeoT::kBatch * W;
+    float *tapl = reinterpret_cast<float *>(twl + W);
+    float *lut = tapl + ((T + 3) & ~3u);
+    constexpr uint32_t kLutElems = (FMT == 1 || FMT == 2) ? 256u : 0u;
+    uint32_t *wq = reinterpret_cast<uint32_t *>(lut + kLutElems) + 4 * GeoT::kBatch;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < 4;
+    {
+        const uint32_t n_tw = W - geo.base_len;
+        for (uint32_t i = tid; i < n_tw; i += NT) twl[i] = P.tw[i];
+        for (uint32_t i = tid; i < T; i += NT) tapl[i] = P.taps[i];
+    }
+    __syncthreads();
+
+    const uint64_t n_tiles = P.n_windows;
+    // tile walk and dynamic tile queue: as in k_chain
+    uint64_t walk_base = 0, walk_local = blockIdx.x, walk_step = gridDim.x, walk_limit = n_tiles;
+    const bool xcd_walk = (gridDim.x & 7u) == 0 && n_tiles >= 8;
+    const uint64_t n8 = (n_tiles + 7) / 8;
+    auto xcd_limit = [&](uint32_t x) -> uint64_t { const uint64_t b = (uint64_t)x * n8; return b >= n_tiles ? 0 : (n_tiles - b < n8 ? n_tiles - b : n8); };
+    if (xcd_walk) {
+        walk_base = (uint64_t)(blockIdx.x & 7u) * n8;
+        walk_local = blockIdx.x >> 3;
+        walk_step = gridDim.x >> 3;
+        walk_limit = xcd_limit(blockIdx.x & 7u);
+    }
+    auto walk_tile = [&](uint64_t local) -> uint64_t { return local < walk_limit ? walk_base + local : n_tiles; };
+    const bool dyn = P.work != nullptr && xcd_walk;
+    const uint32_t my_x = blockIdx.x & 7u;
+    auto claim_resolve = [&](unsigned long long got) -> uint64_t {
+        uint32_t mx = my_x;
+        asm volatile("" : "+s"(mx));
+        if (got < xcd_limit(mx)) return (uint64_t)mx * n8 + got;
+#pragma unroll 1
+        for (uint32_t k = 1; k < 8; ++k) {
+            const uint32_t xx = (mx + k) & 7u;
+            const uint64_t lim = xcd_limit(xx);
+            if (lim == 0) continue;
+            const unsigned long long i = atomicAdd(&P.work[16 * xx], 1ull);
+            if (i < lim) return (uint64_t)xx * n8 + i;
+        }
+        return n_tiles;
+    };
+    uint64_t tile, tile_n;
+    if (dyn) {
+        if (tid == 0) {
+            const uint64_t a = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
+            const uint64_t b = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
+            wq[0] = (uint32_t)a; wq[1] = (uint32_t)(a >> 32); wq[2] = (uint32_t)b; wq[3] = (uint32_t)(b >> 32);
+        }
+        __syncthreads();
+        tile = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
+        tile_n = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[3]) << 32) | __builtin_amdgcn_readfirstlane(wq[2]);
+        __syncthreads();
+    } else {
+        tile = walk_tile(walk_local);
+        tile_n = walk_tile(walk_local + walk_step);
+    }
+
+    // ---- producer state
+    LaneRot lr[SPL];
+    if (HAS_SHIFT && producer) {
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            const uint32_t j = tid * SPL + u;
+            const double2 cs = P.jtab[j];
+            lr[u].jf = (double)j; lr[u].c = cs.x; lr[u].s = cs.y;
+        }
+    }
+    const uint32_t lane_pad = pad_index(geo, tid * SPL);
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    auto n_start_of = [&](uint64_t t) -> uint64_t { return (P.first_window + t) * ((uint64_t)GeoT::S * D); };
+    auto rsrc_of = [&](uint64_t t) {
+        const uint64_t ns = n_start_of(t);
+        const uint64_t left = (P.src_first + P.src_count - ns) * FT::BPS;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * FT::BPS, 0,
+                                                 left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
+    };
+    Vec pf[RCH];
+    auto load_row = [&](const decltype(rsrc_of(0)) &rsrc, int i) {
+        constexpr uint32_t kLastVec = ((kRem * FT::BPS - 1) / VECB) * VECB;
+        uint32_t voff = tid * VECB;
+        if (i + 1 == RCH && kRem != ROW) voff = voff < kLastVec ? voff : kLastVec;
+        constexpr int aux = ct_load_aux(GeoT::kFlags);
+        if constexpr (sizeof(Vec) == 16) {
+            const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), aux);
+            pf[i].x = w.x; pf[i].y = w.y; pf[i].z = w.z; pf[i].w = w.w;
+        } else {
+            const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), aux);
+            pf[i].x = w.x; pf[i].y = w.y;
+        }
+    };
+    double rt_touch = 0.0;
+    // rows [I0, I1) of tile t_cur: consume the prefetched row, park it, refill the slot with the same row of t_refill
+    auto produce = [&](auto i0c, auto i1c, uint64_t t_cur, uint64_t t_refill) {
+        constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+        if constexpr (I0 < I1) {
+            const uint64_t ns = n_start_of(t_cur);
+            const uint64_t t_pf = t_refill < n_tiles ? t_refill : t_cur;           // last tile of this workgroup: harmless re-loads
+            const auto rsrc = rsrc_of(t_pf);
+            const_f64_p rows = (const_f64_p)(uintptr_t)(P.rowtab + (ns / ROW - P.rowtab_row0));
+            if constexpr (HAS_SHIFT && I0 == 0) {                                   // L2 touch of the NEXT tile's row bases (see prefetch_rowtab)
+                uint32_t r = tid < (uint32_t)RCH ? tid : (uint32_t)RCH - 1;
+                asm volatile("" : "+v"(r));
+                rt_touch += P.rowtab[n_start_of(t_pf) / ROW - P.rowtab_row0 + r].c;
+            }
+            TileGeo gl{};
+            gl.tile_raw = kTileRaw;
+            RowBase rb_next{};
+            if constexpr (HAS_SHIFT) rb_next = load_rowbase_at(rows, I0);
+#pragma unroll
+            for (int i = I0; i < I1; ++i) {
+                const Vec v = pf[i];
+                const RowBase rb = rb_next;
+                if constexpr (HAS_SHIFT) { if (i + 1 < I1) rb_next = load_rowbase_at(rows, i + 1); }
+                if (i + 1 < RCH || kRem == ROW) {
+                    process_row<FMT, PT, NCO, true>(P, geo, gl, i * (int)ROW, tid, v, rb, lr, lane_pad, lut, raw);
+                } else {
+                    if (tid * SPL < kRem) process_row<FMT, PT, NCO, (kRem % SPL) == 0>(P, geo, gl, i * (int)ROW, tid, v, rb, lr, lane_pad, lut, raw);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // refill slot i only after row i is consumed (see k_chain)
+                load_row(rsrc, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // ---- consumer: one half of the window's FIR outputs (k = half * HO + lane), scattered for the FFT
+    auto fir_half = [&](uint32_t half, float2 *fb) {
+        uint32_t lane = tid & 63u;
+        asm volatile("" : "+v"(lane));                   // per-lane LDS addresses are rebuilt per step, not hoisted and spilled
+        const uint32_t k = half * HO + lane;
+        uint32_t jmax = (W - k) * D + T / 2;
+        if (jmax > T) jmax = T;
+        const float2 *rp = raw + (size_t)(k + geo.a0) * Dp;
+        const float2 v = fir_pair<GeoT>(rp, jmax, tapl);
+        constexpr uint32_t log_width = 2 * GeoT::layers;
+        const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+        fb[yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
+    };
+
+    // Each role runs its OWN loop (same trip count, three barriers per trip): in one shared loop the producers' prefetch and
+    // lane registers would be live across the consumer's FIR as well and the kernel would need the SUM of the two register
+    // sets instead of the larger one (114 VGPRs against the 96 that five waves per SIMD allow).
+    bool cur_valid = tile < n_tiles;
+    QD_STAMP_DECL
+    auto next_after = [&]() -> uint64_t {                                        // the tile after `tile_n`, read behind step 1's barrier
+        if (dyn) return ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
+        walk_local += walk_step;
+        return walk_tile(walk_local + walk_step);
+    };
+    if (producer) {
+        __builtin_amdgcn_s_setprio(0);
+        if (cur_valid) {
+            const auto rsrc = rsrc_of(tile);
+#pragma unroll
+            for (int i = 0; i < RCH; ++i) load_row(rsrc, i);
+            produce(IntC<0>{}, IntC<RB>{}, tile, tile_n);
+            produce(IntC<RB>{}, IntC<RA + 1>{}, tile, tile_n);
+        }
+        // The claim for the tile after next is one atomic whose reply takes ~1-2 us under load: it is issued a whole step
+        // before its reply is read (behind step 1's barrier it is already needed by every wave).
+        unsigned long long claim = 0;
+        if (dyn && tid == 0) claim = atomicAdd(&P.work[16 * my_x], 1ull);
+        __syncthreads();
+        QD_STAMP_START();
+        while (cur_valid) {
+            produce(IntC<RA + 1>{}, IntC<RCH>{}, tile, tile_n);                    // step 1
+            if (dyn && tid == 0) {
+                const uint64_t t2 = claim_resolve(claim);
+                wq[0] = (uint32_t)t2; wq[1] = (uint32_t)(t2 >> 32);
+            }
+            QD_STAMP_AT(0);
+            __syncthreads();
+            QD_STAMP_AT(1);
+            const uint64_t tile_nn = next_after();
+            const bool next_valid = tile_n < n_tiles;
+            if (dyn && tid == 0 && next_valid) claim = atomicAdd(&P.work[16 * my_x], 1ull);     // read at the end of the next step 1
+            if (next_valid) produce(IntC<0>{}, IntC<RB>{}, tile_n, tile_nn);       // step 2
+            QD_STAMP_AT(2);
+            __syncthreads();
+            QD_STAMP_AT(3);
+            // step 3: the row(s) both halves read.  With the FFT on its own wave nothing else runs meanwhile, so go first.
+            if constexpr (kFftWave) __builtin_amdgcn_s_setprio(3);
+            if (next_valid) produce(IntC<RB>{}, IntC<RA + 1>{}, tile_n, tile_nn);
+            if constexpr (kFftWave) __builtin_amdgcn_s_setprio(0);
+            QD_STAMP_AT(4);
+            __syncthreads();
+            QD_STAMP_AT(5);
+            QD_STAMP_TILE();
+            tile = tile_n; tile_n = tile_nn; cur_valid = next_valid;
+        }
+    } else if (wave == 4) {
+        __builtin_amdgcn_s_setprio(2);
+        uint32_t par = 0;
+        __syncthreads();
+        QD_STAMP_START();
+        while (cur_valid) {
+            float2 *fb = fb0 + (kFftWave ? par * W : 0u);
+            fir_half(0, fb);                                                       // step 1
+            QD_STAMP_AT(0);
+            __syncthreads();
+            QD_STAMP_AT(1);
+            const uint64_t tile_nn = next_after();
+            const bool next_valid = tile_n < n_tiles;
+            fir_half(1, fb);                                                       // step 2
+            QD_STAMP_AT(2);
+            __syncthreads();
+            QD_STAMP_AT(3);
+            if constexpr (!kFftWave) {                                             // step 3
+                __builtin_amdgcn_s_setprio(3);
+                wave_fft_epilogue_fn<GeoT>(P, geo, twl, fb, P.first_window + tile, 1u, tid);
+                __builtin_amdgcn_s_setprio(2);
+            }
+            QD_STAMP_AT(4);
+            __syncthreads();
+            QD_STAMP_AT(5);
+            par ^= 1u;
+            tile = tile_n; tile_n = tile_nn; cur_valid = next_valid;
+        }
+    } else {
+        // the FFT wave: window i-1 (parked in the other slot) during step 1 of window i
+        __builtin_amdgcn_s_setprio(1);
+        uint32_t par = 0;
+        uint64_t prev = n_tiles;
+        __syncthreads();
+        QD_STAMP_START();
+        while (cur_valid) {
+            if (prev < n_tiles) wave_fft_epilogue_fn<GeoT>(P, geo, twl, fb0 + (par ^ 1u) * W, P.first_window + prev, 1u, tid);
+            QD_STAMP_AT(0);
+            __syncthreads();
+            QD_STAMP_AT(1);
+            const uint64_t tile_nn = next_after();
+            const bool next_valid = tile_n < n_tiles;
+            __syncthreads();
+            QD_STAMP_AT(3);
+            __syncthreads();
+            QD_STAMP_AT(5);
+            par ^= 1u;
+            prev = tile;
+            tile = tile_n; tile_n = tile_nn; cur_valid = next_valid;
+        }
+        if (prev < n_tiles) wave_fft_epilogue_fn<GeoT>(P, geo, twl, fb0 + (par ^ 1u) * W, P.first_window + prev, 1u, tid);
+    }
+    QD_STAMP_FLUSH();
+    if (dyn && tid == 0) {       // the last workgroup to leave re-arms the queue for the next launch
+        if (atomicAdd(&P.work[16 * 8], 1ull) == (unsigned long long)gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x <= 8; ++x) P.work[16 * x] = 0;
+        }
+    }
     if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
 }
 

@@ -313,8 +313,10 @@ const FixedEntry kFixed[] = {
     // packed lane-per-output FIR on a 16-byte-row tile (FixedGeo FLAGS_ bit 2, PAD 2): half the VALU instructions of the FIR
     // + row-aligned fast phase 1 (bit 3): buffer loads with a per-tile descriptor, compile-time row offsets
     // + deferred FFT (bit 6, two FFT slots): the previous tile's FFT + epilogue on a wave the FIR leaves idle
-    QD_FIXED_FB(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 76, "cfg3p"),
-    QD_FIXED_FB(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 76, "cfg3p"),
+    // + nt stream loads (bit 8): the slab is read once; the non-temporal policy measured 1.0-1.2 % over the default on three boxes
+    //   (profiles/r03/sweep_cfg3p_load_policy.log; sc0 / sc1 on top of it: nothing)
+    QD_FIXED_FB(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 332, "cfg3p"),
+    QD_FIXED_FB(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 332, "cfg3p"),
     // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
@@ -403,6 +405,10 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         return nullptr;
     }
     char name[512];
+    if (k.flags & kGeoPipe)        // the role-split kernel (k_chain_pipe): 256 producer threads + one consumer wave
+        snprintf(name, sizeof name, "qd::k_chain_pipe<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d, %d>", k.fmt, k.nco, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb, (k.flags & kGeoPipeFftWave) ? 384 : 320);
+    else
     snprintf(name, sizeof name, "qd::k_chain<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %s, %d, %s, true, %d, %d>", k.fmt, k.nco, k.W,
              k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.fir ? "true" : "false", k.rch, k.whole ? "true" : "false", k.lb, k.nt);
     std::string src;
@@ -580,7 +586,8 @@ struct qd_plan {
     const FixedEntry *fixed = nullptr;
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
-    int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0, nt = kThreads;
+    int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0, nt = kThreads;      // nt: threads that share a row of phase 1 (row = nt * SPL samples)
+    int launch_nt = kThreads;            // workgroup size of the main kernel: nt, plus the consumer wave of the role-split kernel
     uint32_t kflags = 0;                 // FixedGeo FLAGS_ of the main kernel
     uint32_t dbg = 0;                    // development builds: ablation bits, read once at plan creation
     // NCO tables: lane tables per plan, row tables per launch context (device path; one per slot of the host ring)
@@ -740,9 +747,9 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         if (part == 0 && (grid & 7u) == 0 && n_tiles >= 4ull * grid) { rc = ensure_work(tabs); if (rc) return rc; P.work = tabs->work; }
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
             void *args[] = {&P};
-            HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->nt, 1, 1, (unsigned)p->geo.lds_bytes, st, args, nullptr));
+            HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->launch_nt, 1, 1, (unsigned)p->geo.lds_bytes, st, args, nullptr));
         } else {
-            hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->nt : kThreads), p->geo.lds_bytes, st, P);
+            hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->launch_nt : kThreads), p->geo.lds_bytes, st, P);
             HIPCHK(hipGetLastError());
         }
     }
@@ -892,7 +899,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 255 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 8191 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -955,6 +962,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     }
     p->geo.G = G;
     p->kflags = kflags;
+    p->launch_nt = p->nt + ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0);
     p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
@@ -988,8 +996,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     int by_lds = (int)(kLdsMax / p->geo.lds_bytes);
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
-    if (p->nt > kThreads) { int by_threads = 2048 / p->nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
-    if (tuned || heavy) { int by_regs = (jit_lb * 4 * 64) / p->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
+    if (p->launch_nt > kThreads) { int by_threads = 2048 / p->launch_nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
+    if (tuned || heavy) { int by_regs = (jit_lb * 4 * 64) / p->launch_nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (tuned && tune[7] && (int)tune[7] < p->wg_per_cu) p->wg_per_cu = (int)tune[7];
     if (const char *e = dev_env("QD_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) p->wg_per_cu = v; }      // development builds
     // Dynamic-LDS limit: the kernels are process-global objects shared by every plan, so the attribute is set to the
@@ -999,7 +1007,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) != hipSuccess)
             p->jit_fn = nullptr;     // fall back to the generic kernel
     }
-    if (heavy && !p->jit_fn) p->nt = kThreads;
+    if (heavy && !p->jit_fn) { p->nt = kThreads; p->launch_nt = kThreads; }
     for (chain_fn f : {p->fn, p->fn_unaligned}) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
         if (e != hipSuccess)
@@ -1168,7 +1176,7 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->raw_step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D;
     info->ratio = p->ratio;
     info->tile_windows = p->geo.G;
-    info->threads = (uint32_t)p->nt;
+    info->threads = (uint32_t)p->launch_nt;
     info->lds_bytes = (uint32_t)p->geo.lds_bytes;
     info->kernel_kind = p->jit_fn ? 2u : (p->fixed ? 1u : 0u);
     return QD_OK;

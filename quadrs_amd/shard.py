@@ -47,23 +47,38 @@ def partition(n_windows, world, raw_step, raw_per_window, tile_windows=1):
     return shards
 
 
-def exchange(own, shards, rank, bytes_per_sample, dist):
-    """Performs the neighbour halo exchange for `rank`; every rank must call it."""
+def alloc_slab(shard, bytes_per_sample, device, torch):
+    """One buffer for everything `shard` reads: its own samples first, room for the halo behind them (filled by exchange)."""
+    return torch.empty(shard.need_count * bytes_per_sample, dtype=torch.uint8, device=device)
+
+
+def exchange(buf, shards, rank, bytes_per_sample, dist):
+    """Performs the neighbour halo exchange for `rank`; every rank must call it.
+
+    `buf` is either the rank's pre-sized slab (alloc_slab: need_count samples, the own part already filled) — the halo is
+    then received straight into its tail and `buf` itself is returned, nothing is copied — or just the own samples, in
+    which case a slab is allocated and the own part copied once (small streams, tests)."""
     import torch
     me = shards[rank]
-    ops, recv_buf = [], None
+    own_b, need_b = me.own_count * bytes_per_sample, me.need_count * bytes_per_sample
+    if buf.numel() == need_b:
+        slab = buf
+    elif buf.numel() == own_b:
+        slab = buf
+        if me.halo and rank + 1 < len(shards):
+            slab = torch.empty(need_b, dtype=torch.uint8, device=buf.device)
+            slab[:own_b] = buf
+    else:
+        raise ValueError(f"buffer of {buf.numel()} bytes is neither the own part ({own_b}) nor the whole slab ({need_b})")
+    ops = []
     if me.halo and rank + 1 < len(shards):
-        recv_buf = torch.empty(me.halo * bytes_per_sample, dtype=torch.uint8, device=own.device)
-        ops.append(dist.P2POp(dist.irecv, recv_buf, rank + 1))
+        ops.append(dist.P2POp(dist.irecv, slab[own_b:need_b], rank + 1))          # a contiguous view: lands in place
     if rank > 0 and shards[rank - 1].halo:
         h = shards[rank - 1].halo
         if h > me.own_count:
             raise ValueError("halo larger than the neighbour's slab: use fewer ranks or a bigger stream")
-        send_buf = own[: h * bytes_per_sample].contiguous()
-        ops.append(dist.P2POp(dist.isend, send_buf, rank - 1))
+        ops.append(dist.P2POp(dist.isend, slab[: h * bytes_per_sample], rank - 1))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    if recv_buf is None:
-        return own
-    return torch.cat([own, recv_buf])
+    return slab

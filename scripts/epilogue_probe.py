@@ -1,6 +1,7 @@
 """Development: cfg2 step time by epilogue (f32 norms 32 MiB out vs glyph codes 8 MiB out vs bucket digits)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import torch
 import quadrs_amd as Q
 N = 1 << 27

@@ -4,6 +4,7 @@ usage: fuzz_shapes.py [n_shapes] [seed] [variants]   (third argument: only geome
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import quadrs_amd as Q
 from util import fuzz_chain_shapes

@@ -1,6 +1,7 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import quadrs_amd as Q
 from oracle import oracle as O
 ratio = Q.shift_ratio(280000, 21000000)

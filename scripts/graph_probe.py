@@ -1,6 +1,7 @@
 """Development: per-step device time of back-to-back qd_plan_run launches, plain stream vs one hipGraph of K steps."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import torch
 import quadrs_amd as Q
 N = 1 << 27

@@ -4,6 +4,7 @@ usage: python3 scripts/host_pinned_trace.py [chunk_MiB]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import quadrs_amd as Q
 N = 1 << 27
 chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 64

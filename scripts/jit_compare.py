@@ -1,6 +1,7 @@
 """Generic vs plan-time-specialised (hiprtc) kernel on a shape that has no built-in FixedGeo build."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import torch
 import quadrs_amd as Q
 N = 1 << 27

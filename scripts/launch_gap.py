@@ -1,6 +1,7 @@
 """Development: what the per-step HIP events in bench.py's timed loop cost (GPU-side gaps between kernels)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import torch
 import quadrs_amd as Q
 N = 1 << 27

@@ -2,6 +2,7 @@
 switch in plan_init and qd_shift)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import numpy as np
 import quadrs_amd as Q
 from oracle import oracle as O

@@ -3,6 +3,7 @@ check each against the generic kernel's output bit for bit.  Backs the plan-time
 quadrs_hip.hip (plan_init)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import torch
 import quadrs_amd as Q
 

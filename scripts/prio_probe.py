@@ -1,6 +1,7 @@
 """Development: wave-priority combinations per phase (phase 1 / FIR / FFT+epilogue), cfg2 and cfg3' shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import torch
 import quadrs_amd as Q
 def run(N, lp, W, skip):

@@ -2,6 +2,7 @@
 Times cfg2-shaped plans with / without the shift stage, with all arithmetic ablated (QD_DEBUG_SKIP=15) or not."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("QUADRS_AMD_HARNESS_ENV", "1")      # QD_* tuning names -> qd_plan_options (quadrs_amd/engine.py)
 import torch
 import quadrs_amd as Q
 N = 1 << 27

@@ -52,6 +52,8 @@ for h, o in zip(a.hints, outs):
 for o in outs[1:]:
     del o
 times = {h: [] for h in a.hints}
+sensors = bench.GpuSensors.for_torch_device(torch, 0)
+power = {h: [] for h in a.hints}
 for r in range(a.rounds):
     for h, p, o in zip(a.hints, plans, outs):
         if p is None:
@@ -66,10 +68,20 @@ for r in range(a.rounds):
         e1.record()
         torch.cuda.synchronize()
         times[h].append(e0.elapsed_time(e1) / a.reps)
+        if sensors.ok() and r == a.rounds - 1:           # power / clock under this variant: ~0.7 s of back-to-back launches
+            t_end = time.perf_counter() + 0.7
+            while time.perf_counter() < t_end:
+                for _ in range(16):
+                    p.run_device(src, o)
+                w, mhz = sensors.read()
+                torch.cuda.synchronize()
+                power[h].append((w, mhz))
 bps = bench.BPS[cfg["fmt"]]
 for h, p in zip(a.hints, plans):
     if p is None:
         continue
     t = np.array(times[h])
     alg = cfg["n"] * bps + p.n_windows * cfg["W"] * 4
-    print(f"{a.workload} {h:28s} median {np.median(t):8.4f} ms  min {t.min():8.4f} ms  hbm_frac(median) {alg / (np.median(t) * 1e-3) / 8e12:.3f}", flush=True)
+    pw = power[h][len(power[h]) // 2:]
+    ptxt = f"  {np.mean([x[0] for x in pw]):6.0f} W {np.mean([x[1] or 0 for x in pw]):5.0f} MHz" if pw else ""
+    print(f"{a.workload} {h:28s} median {np.median(t):8.4f} ms  min {t.min():8.4f} ms  hbm_frac(median) {alg / (np.median(t) * 1e-3) / 8e12:.3f}{ptxt}", flush=True)
