@@ -42,7 +42,7 @@ class PlanInfo(C.Structure):
         ("n_windows", C.c_uint64), ("decimated_len", C.c_uint64), ("out_sample_rate", C.c_uint64),
         ("out_bytes_per_window", C.c_uint64), ("raw_per_window", C.c_uint64), ("raw_step", C.c_uint64),
         ("ratio", C.c_double), ("tile_windows", C.c_uint32), ("threads", C.c_uint32),
-        ("lds_bytes", C.c_uint32), ("kernel_kind", C.c_uint32),
+        ("lds_bytes", C.c_uint32), ("kernel_kind", C.c_uint32), ("kernel_flags", C.c_uint32), ("_reserved", C.c_uint32),
     ]
 
 

@@ -592,9 +592,28 @@ int main(int argc, char **argv) {
             if (g_gpus < 1 || g_gpus > QD_MAX_SHARDS) { usage(); fprintf(stderr, "Error: -gpus takes 1..%d\n", QD_MAX_SHARDS); return 2; }
             args.erase(args.begin(), args.begin() + 2);
         }
+        // -parse-only: print what the grammar (src/args.rs) made of the command line, one operation per line, and stop before
+        // any file or device is touched (tests: filename -> (sample rate, format) guessing, defaults, SI suffixes)
+        bool parse_only = false;
+        if (!args.empty() && args[0] == "-parse-only") { parse_only = true; args.erase(args.begin()); }
         if (args.empty()) { usage(); return 2; }
         std::vector<Op> ops;
         try { ops = parse(args); } catch (const Fail &f) { usage(); fprintf(stderr, "Error: %s\n", f.msg.c_str()); return 2; }
+        if (parse_only) {
+            static const char *fmt_name[] = {"cf32", "cs8", "cu8", "cs16"};
+            for (const Op &op : ops) {
+                switch (op.kind) {
+                case OP_FROM: printf("from file=%s sample_rate=%llu format=%s\n", op.filename.c_str(), (unsigned long long)op.sample_rate, fmt_name[op.format & 3]); break;
+                case OP_GEN: printf("gen cos=%zu sample_rate=%llu seconds=%.17g\n", op.cos.size(), (unsigned long long)op.sample_rate, op.seconds); break;
+                case OP_SHIFT: printf("shift %lld\n", (long long)op.shift); break;
+                case OP_LOWPASS: printf("lowpass frequency=%llu decimate=%llu size=%zu\n", (unsigned long long)op.lp_freq, (unsigned long long)op.decimate, op.size); break;
+                case OP_SPARKFFT: printf("sparkfft width=%zu stride=%llu range=%s\n", op.width, (unsigned long long)op.stride, op.has_range ? "yes" : "no"); break;
+                case OP_BUCKET: printf("bucket width=%zu stride=%llu levels=%zu\n", op.width, (unsigned long long)op.stride, op.levels); break;
+                case OP_WRITE: printf("write prefix=%s overwrite=%d\n", op.prefix.c_str(), op.overwrite ? 1 : 0); break;
+                }
+            }
+            return 0;
+        }
 
         // fold the commands left to right (src/bin/quadrs.rs:48-56)
         std::unique_ptr<Samples> samples;

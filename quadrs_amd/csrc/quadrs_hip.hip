@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <algorithm>
@@ -351,7 +352,10 @@ struct JitKey {
     }
 };
 std::mutex g_jit_mu;
-std::map<JitKey, hipFunction_t> g_jit_cache;
+// A hipFunction_t belongs to the module hipModuleLoadData loaded on the device that was current then: one entry per (device,
+// key).  The on-disk code object is shared, only the load is repeated per device (one-process multi-device plans,
+// qd_plan_options.shard_device[]; that path is unexercised until a multi-GPU box is available — DESIGN.md section 8).
+std::map<std::pair<int, JitKey>, hipFunction_t> g_jit_cache;
 
 std::string csrc_dir() {
     Dl_info info;
@@ -396,7 +400,10 @@ std::string jit_cache_dir() {
 // in-process and on-disk caches are consulted
 hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compile = true, const std::vector<float> *taps = nullptr) {
     std::lock_guard<std::mutex> lock(g_jit_mu);
-    auto it = g_jit_cache.find(k);
+    int jit_dev = 0;
+    (void)hipGetDevice(&jit_dev);
+    const std::pair<int, JitKey> dk(jit_dev, k);
+    auto it = g_jit_cache.find(dk);
     if (it != g_jit_cache.end()) return it->second;
     const std::string dir = csrc_dir();
     std::vector<char> hdr1, hdr2;
@@ -469,7 +476,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
                 hipModule_t mod; hipFunction_t fn = nullptr;
                 if (hipModuleLoadData(&mod, end + 1) == hipSuccess && hipModuleGetFunction(&fn, mod, lowered.c_str()) == hipSuccess) {
                     hiprtcDestroyProgram(&prog);
-                    g_jit_cache[k] = fn;
+                    g_jit_cache[dk] = fn;
                     return fn;
                 }
             }
@@ -509,7 +516,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         }
     }
     hiprtcDestroyProgram(&prog);
-    g_jit_cache[k] = fn;
+    g_jit_cache[dk] = fn;
     return fn;
 }
 
@@ -565,6 +572,13 @@ struct RowTab {
 struct NcoTabs {
     RowTab main, tail;
     unsigned long long *work = nullptr;      // the launch context's tile-queue counters (ChainParams::work), zero between launches
+    // One launch context = one set of tile-queue counters + row tables, so launches that use it are ORDERED even when they
+    // come on different streams: every launch records `done` behind itself, and a launch arriving on another stream waits
+    // for it first (hipStreamWaitEvent, device side).  Two kernels of one context therefore never claim tiles from the same
+    // counters at the same time, and `done` transitively covers every earlier reader of the row tables.
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool launched = false;
 };
 
 struct qd_plan {
@@ -666,6 +680,7 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
                     (unsigned long long)src_first, (unsigned long long)src_count, (unsigned long long)need0,
                     (unsigned long long)need1, (unsigned long long)first_window, (unsigned long long)n_windows);
     int rc = QD_OK;
+    if (tabs->launched && tabs->last_stream != st) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));      // see NcoTabs
     if (p->has_shift) {
         rc = ensure_rowtab_for(p, p->nt * spl_of(fmt), &tabs->main, need0, need1, st);
         if (rc) return rc;
@@ -754,6 +769,9 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         }
     }
     if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
+    if (!tabs->done) HIPCHK(hipEventCreateWithFlags(&tabs->done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(tabs->done, st));
+    tabs->last_stream = st; tabs->launched = true;
 #ifdef QD_WGTIME
     {
         std::vector<unsigned long long> h(kStampWords);
@@ -929,7 +947,45 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // all T taps however few outputs the tile has — so take the largest tile with <= 512 FIR outputs that LDS
     // allows, 512 threads, a 256-VGPR budget and scalar accumulate chains (measured 1.3-2.9x over the small-tile
     // default on six such shapes, scripts/policy_probe.py)
-    bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D;
+    bool auto_variant = false;     // variant flags derived from the geometry, not from the table or a hint
+    // ---- kernel variant from GEOMETRY (plan-time builds of shapes without a built-in kernel).  The variants the built-in
+    // cfg3' / cfg4 kernels use are predicates of the shape, not of a table entry: a chain of 192 taps or W = 256 gets the same
+    // packed FIR, row-aligned phase 1 with non-temporal loads, deferred FFT and (long windows) two-output register tiling
+    // (profiles/r03/shape_sweep.log: 0.45-0.47 of the VALU roof on 160 / 192 / 256 / 384-tap neighbours of cfg3', where the
+    // long-filter policy below reached 0.30-0.35).  The predicates restate FixedGeo's own static conditions (qd_chain.h), so the
+    // build takes the path asked for; if no variant build is to be had the plan falls back to the plain tiling further down.
+    struct { bool valid = false; uint32_t G = 1, batch = 1, flags = 0, firr = 1, firb = 8; int nt = kThreads; } autosel;
+    if (jit_ok && !tuned && !p->fixed && p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && p->S >= p->W) {
+        const uint32_t W = p->W, S = p->S, D = p->D, T = p->T, c_half = T - T / 2;
+        const int spl = spl_of(d.format);
+        auto rows_aligned = [&](uint32_t nt, uint32_t g) {            // fast phase 1: tiles start on a row boundary, <= 10 rows, whole-tile prefetch
+            const uint64_t ROW = (uint64_t)nt * spl, tile_raw = (uint64_t)(g - 1) * S * D + (uint64_t)W * D + T;
+            return ((uint64_t)S * D) % ROW == 0 && (tile_raw + ROW - 1) / ROW <= 10 && D % spl == 0;
+        };
+        const bool pk_geo = T >= 64 && T % 4 == 0 && D % 4 == 0 && is_pow2(D) && c_half % 2 == 0 && (c_half % D) % 2 == 0;
+        const bool tile2_geo = pk_geo && (T / 2) % 4 == 0 && c_half % 4 == 0 && D / 4 <= 8 && T > D + 16 && W % 2 == 0;
+        if (tile2_geo && W >= 512 && (uint64_t)T >= 4ull * D) {
+            // one long window per tile (cfg4's recipe): two outputs per lane as straight-line packed code with in-chain
+            // snapshots, the previous window's FFT + epilogue on idle waves, as many threads as the FIR has lanes for
+            const int nt = W >= 1024 ? 1024 : 512;
+            const uint32_t fl = kGeoPackedTile | kGeoDeferFft | (rows_aligned(nt, 1) ? (kGeoFastP1 | kGeoNtLoads) : 0u);
+            if (lds_for(1, W, S, D, T_lds, nullptr, 2, 2, lut8, fl) <= kLdsMax) {
+                autosel.valid = true; autosel.G = 1; autosel.nt = nt; autosel.batch = 2; autosel.flags = fl; autosel.firr = 2; autosel.firb = 4;
+            }
+        } else if (pk_geo && W <= 256) {
+            // 64..256 outputs per tile of 256 threads (cfg3' recipe): packed lane-per-output FIR on a 16-byte-row tile; where the
+            // FIR leaves a wave idle, the previous tile's FFT + epilogue runs there
+            const uint32_t g = W >= 128 ? 1u : 128u / W;
+            const bool defer = (g * W) % 64 == 0 && g * W + 64 <= 256;
+            const uint32_t fl = kGeoNoSplit | (defer ? kGeoDeferFft : 0u) | (rows_aligned(256, g) ? (kGeoFastP1 | kGeoNtLoads) : 0u);
+            const uint32_t bt = defer ? 2u : 1u;
+            if (p->n_windows >= g && lds_for(g, W, S, D, T_lds, nullptr, 2, bt, lut8, fl) <= kLdsMax / 2) {      // at least two workgroups per CU
+                autosel.valid = true; autosel.G = g; autosel.nt = 256; autosel.batch = bt; autosel.flags = fl;
+            }
+        }
+    }
+    // the long-filter policy serves overlapping windows (shared FIR) and whatever the packed variants above do not take
+    bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D && !autosel.valid;
     int jit_lb = 4, jit_noslp = 0;
     uint32_t pad = 1;              // LDS pad elements per row the main kernel is built with (FixedGeo PAD_)
     if (heavy) {
@@ -959,6 +1015,10 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
         while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
         if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
+        if (autosel.valid) {
+            G = autosel.G; p->nt = autosel.nt; jit_lb = 4; pad = 2; batch = autosel.batch; kflags = autosel.flags; tune[2] = autosel.firr; tune[3] = autosel.firb;
+            auto_variant = true;
+        }
     }
     p->geo.G = G;
     p->kflags = kflags;
@@ -977,6 +1037,19 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         if (want) {
             p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad, batch, kflags), &p->jit_note, may_compile, &p->taps_h);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "tile_hint build failed: %s", p->jit_note.c_str());
+            if (!p->jit_fn && auto_variant) {
+                // no variant build (not cached and too small a stream to compile for, or the build failed): the plain tiling —
+                // which the generic kernels run in as well
+                G = 1; uint32_t re2 = 0;
+                while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
+                while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
+                if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
+                p->nt = kThreads; jit_lb = 4; pad = 1; batch = 1; kflags = 0; tune[2] = 1; tune[3] = 8; auto_variant = false;
+                p->geo.G = G; p->kflags = 0; p->launch_nt = kThreads;
+                p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &re2, 1, 1, lut8, 0);
+                p->geo.lds_raw_elems = re2;
+                p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, 0, 1, 1, 0), &p->jit_note, may_compile, &p->taps_h);
+            }
         }
         // A built-in straight-line FIR kernel (scalar chains of overlapping-window shapes) re-specialised with the plan's OWN filter
         // baked in (taps as immediates: no LDS reads, no registers for them; cfg3 27.8 -> 24.6 ms): worth a compile only for
@@ -997,7 +1070,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->launch_nt > kThreads) { int by_threads = 2048 / p->launch_nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
-    if (tuned || heavy) { int by_regs = (jit_lb * 4 * 64) / p->launch_nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
+    if (tuned || heavy || auto_variant) { int by_regs = (jit_lb * 4 * 64) / p->launch_nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (tuned && tune[7] && (int)tune[7] < p->wg_per_cu) p->wg_per_cu = (int)tune[7];
     if (const char *e = dev_env("QD_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) p->wg_per_cu = v; }      // development builds
     // Dynamic-LDS limit: the kernels are process-global objects shared by every plan, so the attribute is set to the
@@ -1159,7 +1232,7 @@ int qd_plan_destroy(qd_plan *p) {
     if (p->tw_d) (void)hipFree(p->tw_d);
     if (p->jtab_d) (void)hipFree(p->jtab_d);
     if (p->jtab256_d) (void)hipFree(p->jtab256_d);
-    for (NcoTabs *t : {&p->tabs_dev, &p->tabs_slot[0], &p->tabs_slot[1]}) { free_rowtab(&t->main); free_rowtab(&t->tail); if (t->work) (void)hipFree(t->work); t->work = nullptr; }
+    for (NcoTabs *t : {&p->tabs_dev, &p->tabs_slot[0], &p->tabs_slot[1]}) { free_rowtab(&t->main); free_rowtab(&t->tail); if (t->work) (void)hipFree(t->work); t->work = nullptr; if (t->done) (void)hipEventDestroy(t->done); t->done = nullptr; t->launched = false; }
     if (p->ev_made) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
     delete p;
     return QD_OK;
@@ -1179,6 +1252,8 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->threads = (uint32_t)p->launch_nt;
     info->lds_bytes = (uint32_t)p->geo.lds_bytes;
     info->kernel_kind = p->jit_fn ? 2u : (p->fixed ? 1u : 0u);
+    info->kernel_flags = (p->jit_fn || p->fixed) ? p->kflags : 0u;
+    info->_reserved = 0;
     return QD_OK;
 }
 
@@ -1282,12 +1357,18 @@ int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint6
         pend[slot].live = false;
         return QD_OK;
     };
+    // Any error after the first enqueue leaves H2D copies, kernels and D2H copies of earlier chunks in flight — with pinned
+    // buffers the D2H target is the CALLER's memory.  Quiesce both slot streams before handing the status back.
+    auto quiesce = [&](int status) -> int {
+        for (int i = 0; i < 2; ++i) if (p->streams[i]) (void)hipStreamSynchronize(p->streams[i]);
+        return status;
+    };
     int slot = 0;
     for (uint64_t w = first_window; w < first_window + n_windows; w += cw, slot ^= 1) {
         // a staged slot's pinned buffers are reused: wait for its previous chunk; a pinned-to-pinned run only needs
         // stream order (same slot = same stream), so the host runs ahead and just bounds the queue depth
         int rc = (stage_in || stage_out || ((w - first_window) / cw) % 16 >= 14) ? drain(slot) : QD_OK;
-        if (rc) return rc;
+        if (rc) return quiesce(rc);
         const uint64_t nw = first_window + n_windows - w < cw ? first_window + n_windows - w : cw;
         const uint64_t s0 = w * step, cnt = (nw - 1) * step + rpw;
         // keep vector loads aligned: start the slab on a multiple of 8 samples
@@ -1295,7 +1376,7 @@ int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint6
         if (s0a < src_first) s0a = src_first;
         const uint64_t cnta = s0 + cnt - s0a;
         if (s0a < src_first || s0a + cnta > src_first + src_count)
-            return fail(QD_ERR_INVALID, "src slab does not cover the requested windows");
+            return quiesce(fail(QD_ERR_INVALID, "src slab does not cover the requested windows"));
         const uint8_t *hsrc = static_cast<const uint8_t *>(src) + (s0a - src_first) * bps;
         if (stage_in) {
             const double t0 = now_ms();
@@ -1303,17 +1384,20 @@ int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint6
             stage_ms += now_ms() - t0;
             hsrc = static_cast<const uint8_t *>(p->pin_in[slot]);
         }
-        HIPCHK(hipMemcpyAsync(p->dev_in[slot], hsrc, cnta * bps, hipMemcpyHostToDevice, p->streams[slot]));
+        if (hipError_t e = hipMemcpyAsync(p->dev_in[slot], hsrc, cnta * bps, hipMemcpyHostToDevice, p->streams[slot]); e != hipSuccess)
+            return quiesce(fail(QD_ERR_HIP, "hipMemcpyAsync (H2D): %s", hipGetErrorString(e)));
         rc = launch_chain(p, &p->tabs_slot[slot], p->dev_in[slot], s0a, cnta, w, nw, w, p->dev_out[slot], p->streams[slot]);
-        if (rc) return rc;
+        if (rc) return quiesce(rc);
         void *hdst = stage_out ? p->pin_out[slot] : static_cast<void *>(static_cast<uint8_t *>(out) + (w - first_window) * obw);
-        HIPCHK(hipMemcpyAsync(hdst, p->dev_out[slot], nw * obw, hipMemcpyDeviceToHost, p->streams[slot]));
+        if (hipError_t e = hipMemcpyAsync(hdst, p->dev_out[slot], nw * obw, hipMemcpyDeviceToHost, p->streams[slot]); e != hipSuccess)
+            return quiesce(fail(QD_ERR_HIP, "hipMemcpyAsync (D2H): %s", hipGetErrorString(e)));
         pend[slot].live = true; pend[slot].w0 = w; pend[slot].nw = nw;
         p->stats.bytes_h2d += cnta * bps; p->stats.bytes_d2h += nw * obw; p->stats.chunks += 1;
     }
     int rc = drain(0);
-    if (rc) return rc;
+    if (rc) return quiesce(rc);
     rc = drain(1);
+    if (rc) return quiesce(rc);
     p->stats.stage_ms = stage_ms;
     p->stats.wall_ms = now_ms() - t_begin;
     return rc;
@@ -1502,17 +1586,23 @@ struct WsLease {                        // one workspace for the duration of a c
 };
 
 // plans of the FFT-based fine-grained calls, keyed by (device, width, stride, kind)
-struct CachedPlan { int device; uint64_t W, S; int kind; qd_plan *plan; std::mutex mu; };
+// Entries are handed out as shared_ptr: an eviction (cache full) or qd_release_workspaces only drops the CACHE's reference,
+// the plan is destroyed when the last caller still using it lets go — nobody locks a freed mutex or launches on a freed plan.
+struct CachedPlan {
+    int device; uint64_t W, S; int kind; qd_plan *plan; std::mutex mu;
+    CachedPlan(int dev, uint64_t w, uint64_t s, int k, qd_plan *p) : device(dev), W(w), S(s), kind(k), plan(p) {}
+    ~CachedPlan() { if (plan) { DeviceGuard guard(device); (void)qd_plan_destroy(plan); } }
+};
 std::mutex g_pc_mu;
-std::vector<CachedPlan *> g_plan_cache;
+std::vector<std::shared_ptr<CachedPlan>> g_plan_cache;
 constexpr size_t kPlanCacheMax = 32;
 constexpr uint64_t kOpenEnded = 1ull << 40;      // "any number of windows": the cached plans size no loop from it
 
-int cached_fft_plan(uint64_t W, uint64_t S, int kind, CachedPlan **out) {
+int cached_fft_plan(uint64_t W, uint64_t S, int kind, std::shared_ptr<CachedPlan> *out) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_pc_mu);
-    for (CachedPlan *c : g_plan_cache)
+    for (const std::shared_ptr<CachedPlan> &c : g_plan_cache)
         if (c->device == dev && c->W == W && c->S == S && c->kind == kind) { *out = c; return QD_OK; }
     qd_chain_desc d{};
     d.struct_size = sizeof d;
@@ -1532,28 +1622,23 @@ int cached_fft_plan(uint64_t W, uint64_t S, int kind, CachedPlan **out) {
         p->geo.lds_raw_elems = raw_elems;
         p->fn = p->fn_unaligned;
     }
-    if (g_plan_cache.size() >= kPlanCacheMax) {    // evict the oldest entry nobody is using
-        for (size_t i = 0; i < g_plan_cache.size(); ++i) {
-            if (g_plan_cache[i]->mu.try_lock()) {
-                CachedPlan *victim = g_plan_cache[i];
-                g_plan_cache.erase(g_plan_cache.begin() + i);
-                victim->mu.unlock();
-                (void)qd_plan_destroy(victim->plan);
-                delete victim;
-                break;
-            }
-        }
-    }
-    CachedPlan *c = new CachedPlan{dev, W, S, kind, p, {}};
-    g_plan_cache.push_back(c);
-    *out = c;
+    if (g_plan_cache.size() >= kPlanCacheMax) g_plan_cache.erase(g_plan_cache.begin());     // the oldest entry; destroyed once unused
+    g_plan_cache.push_back(std::make_shared<CachedPlan>(dev, W, S, kind, p));
+    *out = g_plan_cache.back();
     return QD_OK;
 }
 
 // ---- Bluestein tables per width (host f64 arithmetic, rounded once to f32), cached per device
-struct BluesteinTab { int device; uint32_t W, M, logM; double2 *chirp, *Bbr, *tw; };
+struct BluesteinTab {
+    int device = 0; uint32_t W = 0, M = 0, logM = 0; double2 *chirp = nullptr, *Bbr = nullptr, *tw = nullptr;
+    BluesteinTab() = default;
+    BluesteinTab(const BluesteinTab &) = delete;
+    BluesteinTab &operator=(const BluesteinTab &) = delete;
+    // hipFree waits for the device: a kernel still reading the tables (its caller has already let go) finishes first
+    ~BluesteinTab() { DeviceGuard guard(device); if (chirp) (void)hipFree(chirp); if (Bbr) (void)hipFree(Bbr); if (tw) (void)hipFree(tw); }
+};
 std::mutex g_bt_mu;
-std::vector<BluesteinTab> g_bt;
+std::vector<std::shared_ptr<BluesteinTab>> g_bt;       // by reference count, like the plan cache: eviction never frees under a caller
 
 void fft64_inplace(std::vector<double> &re, std::vector<double> &im, uint32_t logM) {   // radix-2 DIT, natural order out
     const uint32_t M = 1u << logM;
@@ -1574,12 +1659,13 @@ void fft64_inplace(std::vector<double> &re, std::vector<double> &im, uint32_t lo
     }
 }
 
-int bluestein_tab(uint32_t W, BluesteinTab *out) {
+int bluestein_tab(uint32_t W, std::shared_ptr<BluesteinTab> *out) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_bt_mu);
-    for (const BluesteinTab &t : g_bt) if (t.device == dev && t.W == W) { *out = t; return QD_OK; }
-    BluesteinTab t{};
+    for (const std::shared_ptr<BluesteinTab> &e : g_bt) if (e->device == dev && e->W == W) { *out = e; return QD_OK; }
+    std::shared_ptr<BluesteinTab> tp = std::make_shared<BluesteinTab>();
+    BluesteinTab &t = *tp;
     t.device = dev; t.W = W;
     t.logM = ilog2(2ull * W - 1); t.M = 1u << t.logM;
     const uint32_t M = t.M;
@@ -1608,22 +1694,19 @@ int bluestein_tab(uint32_t W, BluesteinTab *out) {
     HIPCHK(hipMemcpy(t.chirp, chirp.data(), chirp.size() * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t.Bbr, Bbr.data(), Bbr.size() * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t.tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice));
-    if (g_bt.size() >= 64) {                                      // the width slider walks through many lengths: bound the cache
-        (void)hipDeviceSynchronize();
-        (void)hipFree(g_bt[0].chirp); (void)hipFree(g_bt[0].Bbr); (void)hipFree(g_bt[0].tw);
-        g_bt.erase(g_bt.begin());
-    }
-    g_bt.push_back(t);
-    *out = t;
+    if (g_bt.size() >= 64) g_bt.erase(g_bt.begin());               // the width slider walks through many lengths: bound the cache
+    g_bt.push_back(tp);
+    *out = tp;
     return QD_OK;
 }
 
 int bluestein_rows(const float2 *src, uint64_t in_first, const uint64_t *offs_d, const float *win_d, size_t W, size_t n_rows,
                    float *dst, hipStream_t st) {
     if (W > 4096) return fail(QD_ERR_UNSUPPORTED, "take_fft width %zu: widths that are not a power of two are built up to 4096 (the reference front end's slider range, src/eui/mod.rs:157)", W);
-    BluesteinTab t{};
-    int rc = bluestein_tab((uint32_t)W, &t);
+    std::shared_ptr<BluesteinTab> tp;                  // held until the launch is enqueued
+    int rc = bluestein_tab((uint32_t)W, &tp);
     if (rc) return rc;
+    const BluesteinTab &t = *tp;
     if ((size_t)t.M * 16 > 48 * 1024)     // per device, cheap: raise the dynamic-LDS limit to the hardware maximum
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bluestein), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     hipLaunchKernelGGL(k_bluestein, dim3((uint32_t)n_rows), dim3(256), (size_t)t.M * 16, st, src, in_first, offs_d, win_d, (uint32_t)W, t.M, t.logM,
@@ -1652,15 +1735,15 @@ int qd_release_workspaces(void) {
         }
         g_ws_idle.clear();
     }
-    std::lock_guard<std::mutex> lock(g_pc_mu);
-    for (size_t i = 0; i < g_plan_cache.size();) {
-        if (g_plan_cache[i]->mu.try_lock()) {
-            CachedPlan *c = g_plan_cache[i];
-            g_plan_cache.erase(g_plan_cache.begin() + i);
-            c->mu.unlock();
-            (void)qd_plan_destroy(c->plan);
-            delete c;
-        } else ++i;
+    std::vector<std::shared_ptr<CachedPlan>> dropped;
+    {
+        std::lock_guard<std::mutex> lock(g_pc_mu);
+        dropped.swap(g_plan_cache);
+    }
+    dropped.clear();                               // plans nobody is running are destroyed here, the others when their call returns
+    {
+        std::lock_guard<std::mutex> lock(g_bt_mu);
+        g_bt.clear();
     }
     return QD_OK;
 }
@@ -1757,7 +1840,7 @@ int qd_fft_norm_batch(const qd_c32 *in, size_t W, size_t n_fft, size_t in_stride
     if (!in || !norms) return fail(QD_ERR_INVALID, "NULL buffer");
     if (in_stride == 0) return fail(QD_ERR_INVALID, "in_stride 0");
     if (!is_pow2(W)) return fail(QD_ERR_PANIC, "Radix4 requires a power-of-two width (rustfft API contract), got %zu", W);
-    CachedPlan *c = nullptr;
+    std::shared_ptr<CachedPlan> c;
     int rc = cached_fft_plan(W, in_stride, 0, &c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
@@ -1834,7 +1917,7 @@ int qd_take_fft(const qd_c32 *in, uint64_t in_first, size_t n_in, uint64_t sampl
     if (is_pow2(W)) {
         // rustfft's planner gives a power-of-two length to its Radix4 as well: the chain kernel's FFT (bit-exact against
         // the oracle's restatement), rows gathered at irregular offsets by the per-sample kernel
-        CachedPlan *c = nullptr;
+        std::shared_ptr<CachedPlan> c;
         rc = cached_fft_plan(W, W, 1, &c);
         if (rc) return rc;
         std::lock_guard<std::mutex> lock(c->mu);

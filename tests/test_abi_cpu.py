@@ -25,7 +25,7 @@ def test_header_symbols_are_exported(engine):
 
 def test_struct_layout(engine):
     from quadrs_amd import _ffi
-    assert C.sizeof(_ffi.ChainDesc) == 104 and C.sizeof(_ffi.PlanInfo) == 72
+    assert C.sizeof(_ffi.ChainDesc) == 104 and C.sizeof(_ffi.PlanInfo) == 80
 
 
 def test_host_arithmetic_matches_oracle(engine, oracle):
@@ -128,5 +128,11 @@ def test_builtin_kernels_do_not_spill(engine):
     assert len(fixed) >= 8, sorted(res)
     bad = {k: v for k, v in fixed.items() if v.get("VGPRs Spill", 0) > 2 or v.get("ScratchSize", 0) > 16}
     assert not bad, bad
+    # SGPR spills are v_writelane / v_readlane on the vector unit.  The 128-point kernels (cfg2, cfg3') once carried 79-85 of them
+    # — the tile queue's help-the-others loop, unrolled and hoisted out of the tile loop — and now 10-16; the long-filter kernels
+    # (1024 threads, unrolled 400 / 512-tap FIRs) keep more.
+    for k, v in fixed.items():
+        short = "Lj128ELj128E" in k
+        assert v.get("SGPRs Spill", 0) <= (24 if short else 160), (k, v)
     generic = {k: v for k, v in res.items() if "k_chain" in k and "DynGeo" in k}
     assert generic and all(v.get("ScratchSize", 0) <= 256 for v in generic.values()), {k: v for k, v in generic.items() if v.get("ScratchSize", 0) > 256}

@@ -387,12 +387,14 @@ def test_window_subranges_and_slabs_concatenate(engine, oracle, shift, lp, W, S)
         p.run_host(data, p.n_windows - 1, 2)                                            # past the sink's loop
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3p", "cfg4"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3p", "cfg4", "cfg3"])
 def test_full_size_census(engine, oracle, name):
     """EVERY window of the workload at BASELINE.json's full size against the oracle (all host cores, a few seconds): the chains
     without a shift stage must be identical in every bit; with one, all but a handful of windows (an NCO multiplier within
     ~1e-8 f32-ulp of a rounding boundary may round the other way: DESIGN.md section 4), and those within a fraction of an ulp of
-    the window maximum.  cfg3 (16.8 M windows, minutes of host time) is run by scripts/full_census.py: profiles/r02/full_census.log."""
+    the window maximum.  Observed (profiles/r02/full_census.log, profiles/r03): cfg2, cfg3' and cfg4 identical in every bit; cfg3
+    (16.8 M windows, 8.6e9 samples through the NCO, 1.5-3 minutes of host time) all but 8 windows, 0.12 ulp at worst — so the
+    bounds below are 0 windows for the first three and <= 8 windows / 0.2 ulp for cfg3."""
     import bench
     from oracle import oracle as O
     from util import full_size_census
@@ -400,9 +402,14 @@ def test_full_size_census(engine, oracle, name):
     record_observed(f"census {name}", windows=int(total), windows_differing=int(nw), bins_differing=int(nb), worst_ulp_of_window_max=float(worst),
                     oracle_seconds=round(t_cpu, 1), threads=int(cores))
     if bench.WORKLOADS[name]["shift"] is None:
-        assert nw == 0, (nw, nb, worst, first)
+        assert nw == 0, (nw, nb, worst, first)                           # no NCO: every bit
+    elif name == "cfg3":
+        assert nw <= 8 and worst <= 0.2, (nw, nb, worst, first)
     else:
-        assert nw <= max(8, total // 100000) and worst <= 1.0, (nw, nb, worst, first)
+        # 2^27 / 2^31 samples through the NCO: at the observed rate of ~2e-10 rounding-boundary events per sample (cfg3: 2 samples
+        # of 8.6e9) the expectation is 0.03 / 0.5 windows.  Round 2's stream had none; round 3's counter-based stream has one in
+        # cfg3' (window 318984, 20 bins, 0.25 ulp of the window maximum).
+        assert nw <= 2 and worst <= 0.5, (nw, nb, worst, first)
 
 
 def test_device_resident_run_equals_host_run(engine):

@@ -114,6 +114,58 @@ def test_concurrent_runs_on_one_plan(engine):
     assert not errors and all(bits_equal(r, want) for r in results)
 
 
+def test_two_streams_on_one_plan_device_path(engine):
+    """every device-path launch of a plan shares one set of tile-queue counters and row tables.  Two launches of ONE
+    plan on DIFFERENT streams, each big enough for the dynamic tile queue (>= 4 tiles per workgroup of the grid), must not
+    claim tiles from the same counters at the same time: the library orders launches of one launch context across streams
+    (an event wait on the device).  Bit for bit against a single-stream run, several rounds."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    n = 1 << 27                                            # cfg2's shape at full size: 65 535 tiles of two windows >> 4 * 1024
+    cfg = bench.WORKLOADS["cfg2"]
+    src = bench.synth_slab(torch, 0, 0, n, 0x5EED0002, dev)
+    p = engine.Plan(0, cfg["sr"], n, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
+    want = torch.empty(p.n_windows, cfg["W"], dtype=torch.float32, device=dev)
+    p.run_device(src, want)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.zeros_like(want)
+    b = torch.zeros_like(want)
+    for _ in range(4):
+        a.zero_(); b.zero_()
+        torch.cuda.synchronize()
+        p.run_device(src, a, stream=s1.cuda_stream)
+        p.run_device(src, b, stream=s2.cuda_stream)
+        p.run_device(src, a, stream=s1.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), want.view(torch.int32)) and torch.equal(b.view(torch.int32), want.view(torch.int32))
+    # the fine-grained FFT call shares one cached plan between threads with different qd_set_stream streams
+    x = torch.randn(4096 * 128, 2, device=dev)
+    ref = torch.empty(4096, 128, device=dev)
+    import ctypes as C
+    from quadrs_amd import _ffi
+    L = _ffi.lib()
+    _ffi.check(L.qd_fft_norm_batch(C.c_void_p(x.data_ptr()), 128, 4096, 128, C.c_void_p(ref.data_ptr()), _ffi.MEM_DEVICE))
+    torch.cuda.synchronize()
+    outs = [torch.zeros_like(ref) for _ in range(2)]
+    errs = []
+
+    def work(i, stream):
+        try:
+            _ffi.check(L.qd_set_stream(C.c_void_p(stream.cuda_stream)))
+            for _ in range(8):
+                _ffi.check(L.qd_fft_norm_batch(C.c_void_p(x.data_ptr()), 128, 4096, 128, C.c_void_p(outs[i].data_ptr()), _ffi.MEM_DEVICE))
+            _ffi.check(L.qd_set_stream(None))
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i, st)) for i, st in enumerate((s1, s2))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errs and all(torch.equal(o.view(torch.int32), ref.view(torch.int32)) for o in outs)
+
+
 def test_degenerate_sizes(engine, oracle):
     # exactly one admissible window minus one: len == W  ->  the strict `<` loop runs zero times
     x = np.ones((128, 2), dtype=np.float32)
@@ -183,6 +235,17 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 1024, 2, 4, 4, 2, 2 | (200 << 8), 0)),     # the built-in cfg4 kernel's set
     (0, (2_000_000, 16, 256), 256, 256, 310_000, (1, 256, 2, 4, 4, 2, 2 | (192 << 8), 0)),  # other D / T / W, shift on, 256 threads
     (2, (1_000_000, 8, 128), 128, 128, -5_000, (2, 512, 2, 4, 4, 2, 1 | (128 << 8), 0)),    # cu8, G = 2
+    # round 3: the built-in cfg3' set with non-temporal stream loads (bit 8)
+    (0, (200_000, 32, 200), 128, 128, 280_000, (1, 256, 1, 8, 4, 2, 2 | (332 << 8), 0)),
+    # the 4-aligned packed two-output FIR (T = 200: c = 100 is not 8-aligned), taps of output 1 re-read instead of held (D = 32)
+    (0, (200_000, 32, 200), 128, 128, 280_000, (1, 256, 2, 8, 4, 2, 2 | (200 << 8), 0)),
+    (0, (200_000, 32, 200), 128, 128, None, (1, 256, 2, 8, 4, 2, 1 | (128 << 8), 0)),
+    (3, (700_000, 16, 72), 128, 128, 90_000, (1, 256, 2, 8, 4, 2, 2 | (192 << 8), 0)),      # cs16, D = 16 (lag 4: taps held), T/2 = 36
+    # the role-split kernel (k_chain_pipe): four producer waves + the FIR wave (320 threads), and + an FFT wave (384 threads)
+    (0, (200_000, 32, 200), 128, 128, 280_000, (1, 256, 1, 8, 5, 2, 1 | (516 << 8), 0)),
+    (0, (200_000, 32, 200), 128, 128, 280_000, (1, 256, 1, 8, 6, 2, 2 | (1540 << 8), 0)),
+    (0, (2_000_000, 16, 40), 128, 128, 280_000, (1, 256, 1, 8, 6, 2, 2 | (1796 << 8), 0)),    # cfg2's shape: rows 0-1 / 2 / 3-4, nt loads
+    (1, (2_000_000, 16, 40), 128, 128, None, (1, 256, 1, 8, 5, 2, 1 | (516 << 8), 0)),        # cs8 rows of 1024 samples, no shift
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift, hint, epi):
@@ -202,7 +265,9 @@ def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift
     ref_plan = engine.Plan(fmt, 21_000_000, N, kernel_policy=engine.KERNEL_GENERIC, **kw)
     var_plan = engine.Plan(fmt, 21_000_000, N, tile_hint=list(hint), **kw)
     assert ref_plan.info.kernel_kind == 0 and var_plan.info.kernel_kind == 2
-    assert var_plan.info.tile_windows == hint[0] and var_plan.info.threads == hint[1]
+    flags = hint[6] >> 8
+    threads = hint[1] + (0 if not flags & 512 else (128 if flags & 1024 else 64))       # the role-split kernel adds its consumer wave(s)
+    assert var_plan.info.tile_windows == hint[0] and var_plan.info.threads == threads
     a, b = ref_plan.run_host(data), var_plan.run_host(data)
     assert a.shape == b.shape and a.shape[0] in (38, 39)         # bucket: lim / stride windows (src/fft.rs:86), one fewer than sparkfft counts here
     assert a.tobytes() == b.tobytes(), (np.nonzero((a != b).reshape(a.shape[0], -1).any(axis=1))[0][:8],)
@@ -222,6 +287,27 @@ def test_random_shapes_specialised_equals_generic(engine, oracle):
     from util import fuzz_chain_shapes
     checked, bad = fuzz_chain_shapes(Q, 36, 20260101, oracle=oracle)
     assert checked >= 25 and not bad, bad
+
+
+def test_unhinted_plans_select_the_fast_variants(engine, oracle):
+    """the variants of the built-in kernels (packed FIR, row-aligned phase 1, deferred FFT, packed two-output
+    tile) are chosen at plan time from the chain's GEOMETRY.  Random shapes from those families with NO tile hint, specialised
+    build against the generic kernel bit for bit and against the oracle; most of them must come out with non-zero variant flags."""
+    import quadrs_amd as Q
+    from util import fuzz_chain_shapes
+    stats = []
+    checked, bad = fuzz_chain_shapes(Q, 28, 20261004, oracle=oracle, auto_only=True, stats=stats)
+    assert checked >= 20 and not bad, bad
+    flagged = [f for k, f in stats if k == 2 and f != 0]
+    assert len(flagged) >= checked // 3, stats       # the rest: tiles beyond half the LDS, windows of 512+ outputs with short filters, 1024-point windows at D = 32
+    # a shape next to the north_star one (192 taps) and a long-window one: the expected flag sets
+    p = Q.Plan(0, 21_000_000, 1 << 22, shift_hz=280000, lowpass=(200_000, 32, 192), width=128, kernel_policy=Q.KERNEL_SPECIALISE)
+    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (4 | 8 | 64 | 256) and p.info.threads == 256, (p.info.kernel_kind, p.info.kernel_flags)
+    p = Q.Plan(0, 100_000_000, 1 << 24, lowpass=(5_000_000, 8, 384), width=1024, kernel_policy=Q.KERNEL_SPECIALISE)
+    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (128 | 64 | 8 | 256) and p.info.threads == 1024, (p.info.kernel_kind, p.info.kernel_flags)
+    # the policy is not consulted for chains the generic policy must keep: overlapping windows, tiny filters
+    p = Q.Plan(0, 21_000_000, 1 << 22, lowpass=(2_000_000, 16, 24), width=128, kernel_policy=Q.KERNEL_SPECIALISE)
+    assert p.info.kernel_flags == 0
 
 
 def test_plan_time_builds_are_cached_on_disk(tmp_path):

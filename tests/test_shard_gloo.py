@@ -74,6 +74,67 @@ def test_sharded_equals_whole(tmp_path, oracle, world, cfg):
     assert np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
 
 
+def _hip_worker(rank, world, port, n, cfg, out_dir):
+    """One rank of the HIP-path test: both ranks on cuda:0, gloo between them, the halo exchanged in place into the pre-sized
+    slab (as bench.py does over RCCL), the rank's window range through the HIP chain kernel."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import quadrs_amd as Q
+    from quadrs_amd import shard as SH
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shift, (fc, D, T), W, S = cfg
+    rng = np.random.default_rng(4321)
+    x = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)       # every rank can rebuild the stream
+    plan = Q.Plan(0, 21_000_000, n, shift_hz=shift, lowpass=(fc, D, T), width=W, stride=S)
+    info = plan.info
+    shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, info.tile_windows)
+    me = shards[rank]
+    host = SH.alloc_slab(me, 8, "cpu", torch)
+    host[:me.own_count * 8] = torch.from_numpy(x[me.own_first:me.own_first + me.own_count].copy()).view(torch.uint8).reshape(-1)
+    got = SH.exchange(host, shards, rank, 8, dist)
+    assert got.data_ptr() == host.data_ptr()                           # received in place: no second slab
+    assert np.array_equal(host.numpy().view(np.float32).reshape(-1, 2), x[me.need_first:me.need_first + me.need_count])
+    slab = host.cuda()
+    nw = me.w1 - me.w0
+    out = torch.empty(nw, W, dtype=torch.float32, device="cuda")
+    plan.run_device(slab, out, me.w0, nw, src_first=me.need_first, src_count=me.need_count)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"hip_rank{rank}.npy"), out.cpu().numpy())
+    np.save(os.path.join(out_dir, f"hip_kind{rank}.npy"), np.array([int(info.kernel_kind), int(info.tile_windows)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.spawns_gpu_ranks
+@pytest.mark.parametrize("world,cfg,n", [
+    (2, (280000, (200_000, 32, 400), 64, 16), 3_000_000),      # cfg 5's chain (built-in long-filter kernel, 27-window tiles): halo 1936 samples
+    (2, (280000, (200_000, 32, 200), 128, 128), 6_000_000),    # the north_star chain (built-in kernel): halo 200 samples
+    (3, (280000, (2_000_000, 16, 40), 128, 128), 2_000_000),   # cfg 2's chain, three ranks
+])
+def test_sharded_hip_ranks_equal_single_rank(tmp_path, world, cfg, n):
+    """The multi-rank path with the HIP kernels: `world` rank processes (gloo, all on cuda:0) each run their window range from
+    their own slab + exchanged halo; the concatenation must equal the single-rank HIP run bit for bit.  Scheduled before any
+    test that initialises the GPU in this process (conftest.py: spawns_gpu_ranks)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_hip_worker, args=(world, port, n, cfg, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import quadrs_amd as Q
+    shift, (fc, D, T), W, S = cfg
+    rng = np.random.default_rng(4321)
+    x = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)
+    plan = Q.Plan(0, 21_000_000, n, shift_hz=shift, lowpass=(fc, D, T), width=W, stride=S)
+    whole = plan.run_host(x.tobytes())
+    parts = np.concatenate([np.load(os.path.join(str(tmp_path), f"hip_rank{r}.npy")) for r in range(world)])
+    assert parts.shape == whole.shape
+    assert np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
+
+
 def test_partition_properties():
     from quadrs_amd import shard as SH
     for n_windows, world, step, rpw, tile in ((65535, 8, 2048, 2088, 2), (16777212, 8, 512, 2448, 4), (10, 4, 8, 40, 1),

@@ -48,7 +48,7 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=False):
+def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=False, auto_only=False, stats=None):
     """Random chain shapes through the plan-time compiler (QD_JIT=1; a quarter of them with a QD_TUNE tiling that
     exercises the register-tiled FIR / 16-byte LDS rows / wide workgroups) against the generic kernel (QD_JIT=0),
     bit for bit; with `oracle` (tests only) the first windows are also checked against the CPU oracle: bit-exact without
@@ -65,6 +65,12 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=Fa
             S = int(rng.choice([W, W, max(1, W // 2), max(1, W // 4), int(rng.integers(1, 2 * W + 1))]))
             D = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 32, 64]))
             T = int(rng.choice([2, 8, 9, 16, 40, 48, 64, 100, 128, 200, 256, 400, 512, 800]))
+            if auto_only:                           # the families the plan-time variant selection serves, NO hint: the library chooses
+                W = int(rng.choice([64, 128, 256, 512, 1024]))
+                S = W
+                D = int(rng.choice([4, 8, 16, 32]))
+                T = int(rng.choice([64, 72, 96, 128, 160, 192, 200, 256, 384, 400, 512]))
+                fmt = int(rng.choice([0, 0, 1, 3]))
             if variants_only:                       # geometries the FLAGS_ variants apply to, every shape with a variant tiling
                 D = int(rng.choice([8, 16, 32, 64]))
                 T = int(rng.choice([32, 40, 48, 64, 96, 128, 200, 256, 400, 512, 800]))
@@ -79,7 +85,9 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=Fa
             if fmt == 0:
                 data = (rng.standard_normal((N, 2)).astype(np.float32) * 0.05).view(np.uint8).reshape(-1)
             tune = None
-            if not variants_only and rng.random() < 0.25 and D % 8 == 0 and T % 16 == 0:
+            if auto_only:
+                pass
+            elif not variants_only and rng.random() < 0.25 and D % 8 == 0 and T % 16 == 0:
                 tune = "%d:%d:%d:8:%d:%d" % (rng.integers(1, 4), rng.choice([256, 512, 1024]), rng.choice([1, 2]), rng.choice([2, 4]),
                                             rng.choice([1, 2]))
             elif (variants_only or rng.random() < 0.35) and D % 8 == 0 and T % 8 == 0 and T >= 32:
@@ -104,7 +112,9 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=Fa
                         tune = None
                         p = Q.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=(1_000_000, D, T), width=W, stride=S, epilogue=epi)
                     outs[mode] = p.run_host(data)
-                    info[mode] = (p.info.kernel_kind, p.info.tile_windows, p.info.threads)
+                    info[mode] = (p.info.kernel_kind, p.info.tile_windows, p.info.threads, p.info.kernel_flags)
+                    if stats is not None and mode == "1":
+                        stats.append((int(p.info.kernel_kind), int(p.info.kernel_flags)))
                 except Q.QuadrsError as e:
                     outs[mode] = str(e)
             a, b = outs["0"], outs["1"]
