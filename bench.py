@@ -483,7 +483,7 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
         if power:
             roof["power"] = power
         res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
-               "outputs_finite": finite, "seams_verified": seams, "kernel_kind": int(info.kernel_kind), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
+               "outputs_finite": finite, "seams_verified": seams, "kernel_kind": int(info.kernel_kind), "kernel_flags": int(info.kernel_flags), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
         if with_cpu:
             nwin_cpu = int(min(nw, max(64, (1 << 30) // (info.raw_step * bps))))     # at most 1 GiB of the stream goes to the host
             first, count = plan.src_range(me.w0 + (nw - nwin_cpu) // 2, nwin_cpu)
@@ -653,7 +653,7 @@ def main():
             "config": {"workload": f"{args.workload}: {workload_desc(cfg)}", "samples_per_gpu": cfg["n"], "taps": cfg["lp"][2],
                        "decimate": cfg["lp"][1], "width": cfg["W"], "stride": cfg["S"],
                        "parallelism": f"window-range shards x{world}, halo {(cfg['W'] - cfg['S']) * cfg['lp'][1] + cfg['lp'][2]} samples",
-                       "outputs_finite": main_res["outputs_finite"], "kernel_kind": main_res["kernel_kind"],
+                       "outputs_finite": main_res["outputs_finite"], "kernel_kind": main_res["kernel_kind"], "kernel_flags": main_res["kernel_flags"],
                        "tile_windows": main_res["tile_windows"], "threads": main_res["threads"]},
             "roofline": main_res["roofline"],
         }

@@ -141,6 +141,7 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
 constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32,
                    kGeoDeferFft = 64, kGeoPackedTile = 128, kGeoNtLoads = 256;   // FixedGeo FLAGS_ bits
 // cache policy (buffer-load aux operand) of the phase-1 stream loads: bit 8 -> nt, bits 11 / 12 -> sc0 / sc1
+constexpr uint32_t kGeoHalfTile = 8192;      // FLAGS_ bit 13: the tile buffer holds HALF a window's FIR input, two passes per window (see FixedGeo::kHalfTile)
 constexpr int ct_load_aux(uint32_t flags) { return ((flags & 256u) ? 2 : 0) | ((flags & 2048u) ? 1 : 0) | ((flags & 4096u) ? 16 : 0); }
 typedef float v2f __attribute__((ext_vector_type(2)));      // operand type of the v_pk_*_f32 instructions
 
@@ -199,7 +200,22 @@ struct FixedGeo {
     static constexpr uint32_t log_base = logW <= 3 ? logW : ((logW & 1) ? 3u : 4u);
     static constexpr uint32_t base_len = 1u << log_base;
     static constexpr uint32_t layers = (logW - log_base) / 2;
-    static constexpr uint32_t lds_raw_elems_std = ct_raw_elems(W_, S_, D_, T_, G_, kPad ? kPad : 1);
+    // Half-window tiles (FLAGS_ bit 13; one long window per tile, non-overlapping): the raw buffer holds the input of HALF the
+    // window's outputs (c + (W/2 - 1) D + T samples) and a window is filtered in two passes — phase 1 + FIR of outputs [0, W/2),
+    // then of [W/2, W) — into one FFT slot.  The tile is half as large, so TWO workgroups fit on a CU where one did (cfg4: 97 KiB ->
+    // 62 KiB), and one workgroup's phase 1 and barriers run while the other's FIR has the vector units: the 8 k serial cycles in
+    // front of every 21 k-cycle FIR of the one-workgroup form overlap.  Every output sees the same samples, taps and order.
+    static constexpr bool kHalfTile = (FLAGS_ & kGeoHalfTile) && G_ == 1 && !(T_ > 0 && S_ < W_) && W_ % 4 == 0 && T_ > 0;
+    static constexpr uint32_t kHalfOut = W_ / 2;
+    static constexpr uint32_t kHalfRaw = (T_ - T_ / 2) + (kHalfOut - 1) * D_ + T_;
+    static constexpr uint32_t ct_half_elems() {
+        const uint32_t pad = (D_ % 2 == 0) ? (kPad ? kPad : 1) * (kHalfRaw / D_ + 1) : 0;
+        uint32_t elems = kHalfRaw + pad + 1;
+        const uint32_t min_elems = G_ * W_ / 2 + 1;
+        if (elems < min_elems) elems = min_elems;
+        return (elems + 1) & ~1u;
+    }
+    static constexpr uint32_t lds_raw_elems_std = kHalfTile ? ct_half_elems() : ct_raw_elems(W_, S_, D_, T_, G_, kPad ? kPad : 1);
     static constexpr uint32_t kNtrunc = c ? (c + D_ - 1) / D_ - 1 : 0;
     static constexpr bool kShared = T_ > 0 && S_ < W_ && kNtrunc <= S_;     // shared-FIR mode (see phase 2)
     // component-split FIR (fir_comp): mid-length filters whose tile leaves at least half the lanes without an output
@@ -231,7 +247,8 @@ struct DynGeo {
     static constexpr bool kFixed = false;
     static constexpr uint32_t kBatch = 1;
     static constexpr uint32_t kFlags = 0, G_ct = 1, W_ct = 1;
-    static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false, kUnrolledShared = false, kPackedTile = false;
+    static constexpr bool kPlanar = false, kBakedTaps = false, kPairFir = false, kUnrolledShared = false, kPackedTile = false, kHalfTile = false;
+    static constexpr uint32_t kHalfOut = 0, kHalfRaw = 0;
     static constexpr uint32_t DpP = 0, plane_floats = 0;
     static constexpr bool kShared = false;
     static constexpr uint32_t kFirTile = 1;
@@ -292,7 +309,7 @@ __device__ __forceinline__ TileGeo tile_geo(const ChainParams &P, const GeoT &ge
 // stay in bounds, there is no branch, and the load writes its destination register directly —
 // nothing forces an early s_waitcnt.  The host never hands this path a vector that straddles the
 // slab end.  !ALIGNED (slab start not vector aligned): per-sample loads, correctness path.
-template <int FMT, int NT, bool ALIGNED>
+template <int FMT, int NT, bool ALIGNED, bool NTLOAD = false>
 __device__ __forceinline__ typename FmtTraits<FMT>::Vec fetch_row(const ChainParams &P, const TileGeo &g, uint32_t i,
                                                                     uint32_t tid) {
     using FT = FmtTraits<FMT>;
@@ -317,6 +334,14 @@ __device__ __forceinline__ typename FmtTraits<FMT>::Vec fetch_row(const ChainPar
         t = t < lo_rel ? lo_rel : t;
         t = t > hi_rel ? hi_rel : t;
         const uint8_t *rowp = P.src + row_off;                                                     // uniform base
+        if constexpr (NTLOAD) {                       // the stream is read once: non-temporal policy (FixedGeo FLAGS_ bit 8)
+            typedef unsigned vnt4 __attribute__((ext_vector_type(4)));
+            typedef unsigned vnt2 __attribute__((ext_vector_type(2)));
+            Vec v;
+            if constexpr (sizeof(Vec) == 16) { const vnt4 w = __builtin_nontemporal_load(reinterpret_cast<const vnt4 *>(rowp + t)); v.x = w.x; v.y = w.y; v.z = w.z; v.w = w.w; }
+            else { const vnt2 w = __builtin_nontemporal_load(reinterpret_cast<const vnt2 *>(rowp + t)); v.x = w.x; v.y = w.y; }
+            return v;
+        }
         return *reinterpret_cast<const Vec *>(rowp + t);
     } else {
         const int32_t m0 = g.rel0 + (int32_t)(i * (NT * SPL)) + (int32_t)(tid * SPL);
@@ -1260,7 +1285,7 @@ template <class GeoT, bool HAS_FIR>
 constexpr bool defer_fft_ok(uint32_t nt) {
     if constexpr (!GeoT::kFixed) return false;
     else {
-        constexpr uint32_t GW = GeoT::G * GeoT::W, FL = GeoT::kPackedTile ? GW / 2 : GW;       // lanes the FIR occupies
+        constexpr uint32_t GW = GeoT::kHalfTile ? GeoT::kHalfOut : GeoT::G * GeoT::W, FL = GeoT::kPackedTile ? GW / 2 : GW;       // lanes the FIR occupies
         return HAS_FIR && (GeoT::kPairFir || GeoT::kPackedTile) && (GeoT::kFlags & kGeoDeferFft) != 0 && GeoT::kBatch == 2 && FL % 64 == 0 && FL + 64 <= nt;
     }
 }
@@ -1270,7 +1295,7 @@ template <class GeoT, bool HAS_FIR>
 constexpr bool quad_fft_ok(uint32_t nt) {
     if constexpr (!GeoT::kFixed) return false;
     else {
-        constexpr uint32_t GW = GeoT::G * GeoT::W, FL = GeoT::kPackedTile ? GW / 2 : GW;
+        constexpr uint32_t GW = GeoT::kHalfTile ? GeoT::kHalfOut : GeoT::G * GeoT::W, FL = GeoT::kPackedTile ? GW / 2 : GW;
         return defer_fft_ok<GeoT, HAS_FIR>(nt) && GeoT::G == 1 && GeoT::W >= 256 && GeoT::layers >= 1 && GeoT::base_len >= 8 && FL + 4 * 64 <= nt;
     }
 }
@@ -1281,8 +1306,9 @@ constexpr bool fast_p1_ok(int rch, bool whole, bool aligned) {
     if constexpr (!GeoT::kFixed) return false;
     else {
         constexpr uint32_t ROW = NT * FmtTraits<FMT>::SPL;
-        constexpr uint32_t tile_raw = (GeoT::G - 1) * GeoT::S * GeoT::D + GeoT::W * GeoT::D + GeoT::T;
-        return whole && aligned && (GeoT::S * GeoT::D) % ROW == 0 && (uint32_t)rch == (tile_raw + ROW - 1) / ROW && GeoT::D % FmtTraits<FMT>::SPL == 0 &&
+        constexpr uint32_t tile_raw = GeoT::kHalfTile ? GeoT::kHalfRaw : (GeoT::G - 1) * GeoT::S * GeoT::D + GeoT::W * GeoT::D + GeoT::T;
+        constexpr uint32_t step = GeoT::kHalfTile ? GeoT::kHalfOut * GeoT::D : GeoT::S * GeoT::D;      // raw samples between consecutive passes
+        return whole && aligned && step % ROW == 0 && (GeoT::S * GeoT::D) % ROW == 0 && (uint32_t)rch == (tile_raw + ROW - 1) / ROW && GeoT::D % FmtTraits<FMT>::SPL == 0 &&
                (GeoT::kFlags & kGeoFastP1);
     }
 }
@@ -1333,6 +1359,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     // (the table is L2-resident; a tile of such a shape costs tens of thousands of cycles).
     constexpr bool kReloadLane = HAS_SHIFT && GeoT::kFixed && GeoT::kFirTile > 1;
     constexpr bool kFastP1 = fast_p1_ok<FMT, NT, GeoT>(RCH, WHOLE, ALIGNED);
+    constexpr bool kHalf = GeoT::kHalfTile;                 // two passes per window (FixedGeo::kHalfTile); `half` = the pass this iteration runs
+    static_assert(!kHalf || (kFastP1 && defer_fft_ok<GeoT, HAS_FIR>((uint32_t)NT)), "half-window tiles: row-aligned phase 1 and the deferred FFT");
+    uint32_t half = 0;
     LaneRot lr[SPL];
     auto load_lane_rot = [&](uint32_t first) {
 #pragma unroll
@@ -1391,37 +1420,28 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         // a v_readlane on the FIR wave between its last tap and the barrier the whole workgroup waits at).
         uint32_t mx = my_x;
         asm volatile("" : "+s"(mx));
-        if (got < xcd_limit(mx)) return (uint64_t)mx * n8 + got;
+        // every workgroup walks its first TWO tiles statically (no atomic round trip and no hand-over barriers in front of the
+        // first loads); the counters hand out what lies behind those two rounds of each group
+        const uint64_t dyn_base = 2 * walk_step;
+        if (got + dyn_base < xcd_limit(mx)) return (uint64_t)mx * n8 + dyn_base + got;
 #pragma unroll 1
         for (uint32_t k = 1; k < 8; ++k) {                                // own eighth exhausted: help the others
             const uint32_t xx = (mx + k) & 7u;
             const uint64_t lim = xcd_limit(xx);
-            if (lim == 0) continue;
+            if (lim <= dyn_base) continue;
             const unsigned long long i = atomicAdd(&P.work[16 * xx], 1ull);
-            if (i < lim) return (uint64_t)xx * n8 + i;
+            if (i + dyn_base < lim) return (uint64_t)xx * n8 + dyn_base + i;
         }
         return n_tiles;
     };
     uint64_t tile, tile_n;                                                // this tile and the next one (wave-uniform)
-    if (dyn) {
-        if (tid == 0) {
-            const uint64_t a = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
-            const uint64_t b = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
-            wq[0] = (uint32_t)a; wq[1] = (uint32_t)(a >> 32); wq[2] = (uint32_t)b; wq[3] = (uint32_t)(b >> 32);
-        }
-        __syncthreads();
-        tile = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
-        tile_n = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[3]) << 32) | __builtin_amdgcn_readfirstlane(wq[2]);
-        __syncthreads();                                                  // wq is rewritten inside the loop
-    } else {
-        tile = walk_tile(walk_local);
-        tile_n = walk_tile(walk_local + walk_step);
-    }
+    tile = walk_tile(walk_local);                                         // static for the first two rounds, dynamic or static after
+    tile_n = walk_tile(walk_local + walk_step);
     TileGeo tg = tile_geo<FMT, NT>(P, geo, tile, n_tiles);
     Vec pf[RCH];
     if (tg.valid) {
 #pragma unroll
-        for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, NT, ALIGNED>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
+        for (int i = 0; i < RCH; ++i) pf[i] = fetch_row<FMT, NT, ALIGNED, (GeoT::kFlags & kGeoNtLoads) != 0>(P, tg, (uint32_t)i < tg.n_rows ? i : tg.n_rows - 1, tid);
     }
 
 #ifdef QD_WGTIME       // diagnostic build: when each workgroup started / finished (100 MHz realtime counter) and on which XCD
@@ -1532,7 +1552,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             load_lane_rot(first);
         }
         unsigned long long claim = 0;
-        if (dyn && tid == 0) claim = atomicAdd(&P.work[16 * my_x], 1ull);     // the tile after next; the reply is read after the FIR
+        if (dyn && tid == 0 && (!kHalf || half == 1)) claim = atomicAdd(&P.work[16 * my_x], 1ull);     // the tile after next; the reply is read after the FIR
         if constexpr (kFastP1) {
             // Row-aligned tiles (S*D a multiple of the row length, the tile a compile-time number of rows, full tiles only — the
             // host sends a short last tile to the per-sample kernel): every row offset is an immediate, the loads go through a
@@ -1540,10 +1560,12 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             // reads as zero and is never used), interior rows carry no bounds logic and only the last row is predicated, with a
             // compile-time extent.  ~250 fewer scalar / vector instructions per tile and wave than the general path below.
             constexpr uint32_t ROWB = NT * SPL * FT::BPS, VECB = SPL * FT::BPS;
-            constexpr uint32_t kTileRaw = (GeoT::G - 1) * GeoT::S * GeoT::D + GeoT::W * GeoT::D + GeoT::T;
+            constexpr uint32_t kTileRaw = kHalf ? GeoT::kHalfRaw : (GeoT::G - 1) * GeoT::S * GeoT::D + GeoT::W * GeoT::D + GeoT::T;
             constexpr uint32_t kRem = kTileRaw - (RCH - 1) * (NT * SPL);          // samples in the last row
-            const uint64_t tile_pf = tile_n < n_tiles ? tile_n : tile;             // last tile of this workgroup: harmless re-loads
-            const uint64_t ns_n = (P.first_window + tile_pf * GeoT::G) * ((uint64_t)GeoT::S * GeoT::D);
+            constexpr uint32_t kHalfStep = GeoT::kHalfOut * GeoT::D;               // raw samples from a window's first pass to its second
+            uint64_t tile_pf = tile_n < n_tiles ? tile_n : tile;                   // last tile of this workgroup: harmless re-loads
+            if (kHalf && half == 0) tile_pf = tile;                                // the next pass is this window's second half
+            const uint64_t ns_n = (P.first_window + tile_pf * GeoT::G) * ((uint64_t)GeoT::S * GeoT::D) + ((kHalf && half == 0) ? kHalfStep : 0u);
             const uint64_t left = (P.src_first + P.src_count - ns_n) * FT::BPS;
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns_n - P.src_first) * FT::BPS, 0,
                                                                 left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
@@ -1552,7 +1574,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 asm volatile("" : "+v"(r));
                 rt_pf = P.rowtab[ns_n / (NT * SPL) - P.rowtab_row0 + r].c;          // L2 touch of the next tile's row bases (see prefetch_rowtab)
             }
-            const_f64_p rows = (const_f64_p)(uintptr_t)(P.rowtab + (tg.r0 - P.rowtab_row0));
+            const_f64_p rows = (const_f64_p)(uintptr_t)(P.rowtab + (tg.r0 + (kHalf ? half * (kHalfStep / (NT * SPL)) : 0u) - P.rowtab_row0));
             RowBase rb_next{};
             if constexpr (HAS_SHIFT) rb_next = load_rowbase_at(rows, 0);
             TileGeo gl = tg;
@@ -1615,7 +1637,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 // loop's back edge with register copies behind an s_waitcnt vmcnt(0) — a full drain of the next tile's
                 // prefetch at the end of every tile.
                 __builtin_amdgcn_sched_barrier(0);
-                pf[i] = fetch_row<FMT, NT, ALIGNED>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
+                pf[i] = fetch_row<FMT, NT, ALIGNED, (GeoT::kFlags & kGeoNtLoads) != 0>(P, ng, (uint32_t)i < ng.n_rows ? i : ng.n_rows - 1, tid);
                 QD_STAMP_ROW(1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1632,7 +1654,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 }
 #pragma unroll
                 for (int i = 0; i < RCH; ++i)
-                    pf[i] = fetch_row<FMT, NT, ALIGNED>(P, ng, rbase + i < ng.n_rows ? rbase + i : ng.n_rows - 1, tid);
+                    pf[i] = fetch_row<FMT, NT, ALIGNED, (GeoT::kFlags & kGeoNtLoads) != 0>(P, ng, rbase + i < ng.n_rows ? rbase + i : ng.n_rows - 1, tid);
                 RowBase rb[RCH];
 #pragma unroll
                 for (int i = 0; i < RCH; ++i) {
@@ -1650,20 +1672,21 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
 
         __builtin_amdgcn_s_setprio(1);
         if constexpr (kDefer) {
-            constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct, FL = GeoT::kPackedTile ? GW / 2 : GW;
+            constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct, GWP = kHalf ? GeoT::kHalfOut : GW, FL = GeoT::kPackedTile ? GWP / 2 : GWP;      // GWP: outputs of one pass
             float2 *fb_cur = fb0 + (size_t)dpar * GW, *fb_prev = fb0 + (size_t)(dpar ^ 1u) * GW;
-            const uint32_t n_out_d = g_cnt << logW;
+            const uint32_t n_out_d = kHalf ? GWP : (g_cnt << logW);
             const uint32_t log_width_d = 2 * geo.layers;
+            const uint32_t k_first = kHalf ? half * GWP : 0u;  // first output of this pass; the raw buffer starts at ITS first sample
             if (tid < FL) {                                    // the FIR waves
                 if constexpr (GeoT::kPackedTile) {             // two outputs per lane, truncated ones as in-chain snapshots
                     const uint32_t o0 = tid * 2;
                     if (o0 < n_out_d) {
-                        const uint32_t g = o0 >> logW, k0 = o0 & (W - 1);
+                        const uint32_t g = kHalf ? 0u : (o0 >> logW), k0 = kHalf ? k_first + o0 : (o0 & (W - 1));
                         uint32_t jm[2];
 #pragma unroll
                         for (int r = 0; r < 2; ++r) { const uint32_t j2 = (W - (k0 + r)) * D + T / 2; jm[r] = j2 < T ? j2 : T; }
                         float2 full[2], snp[2];
-                        const uint32_t q0 = g * S + k0;
+                        const uint32_t q0 = kHalf ? o0 : g * S + k0;
                         if ((tid >> 8) & 1u) fir_tiled2_pk<GeoT, 1>(raw + (q0 * D + GeoT::kPad * (q0 / 2)), tapl, full, jm, snp); else fir_tiled2_pk<GeoT, 0>(raw + (q0 * D + GeoT::kPad * (q0 / 2)), tapl, full, jm, snp);
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
@@ -1673,14 +1696,15 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                         }
                     }
                 } else if (tid < n_out_d) {                    // one lane per complex output
-                    const uint32_t g = tid >> logW, k = tid & (W - 1);
+                    const uint32_t g = kHalf ? 0u : (tid >> logW), k = kHalf ? k_first + tid : (tid & (W - 1));
                     uint32_t jmax = (W - k) * D + T / 2;
                     if (jmax > T) jmax = T;
-                    const float2 *rp = raw + (size_t)(g * S + k + geo.a0) * Dp;
+                    const float2 *rp = raw + (size_t)((kHalf ? tid : g * S + k) + geo.a0) * Dp;
                     const float2 v = QD_DBG(P, 2) ? rp[0] : fir_pair<GeoT>(rp, jmax, tapl);      // dbg: timing-only ablation
                     const uint32_t xx = k & ((1u << log_width_d) - 1), yy = k >> log_width_d;
                     fb_cur[(g << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = v;
                 }
+            } else if (kHalf && half != 0) {                   // the previous window was transformed beside this window's first pass
             } else if (kQuadFft && P.epi != 2) {               // one long window: four spare waves share its FFT + epilogue
                 if ((tid >> 6) < FL / 64 + 4 && dprev_valid) {
                     __builtin_amdgcn_s_setprio(3);
@@ -1691,6 +1715,16 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 wave_fft_epilogue(fb_prev, dprev_w0, dprev_gcnt);
             }
             QD_STAMP_AT(2);
+            if constexpr (kHalf) {
+                if (half == 0) {                               // second pass of the same window next: no tile advance
+                    __syncthreads();                           // the raw buffer is free, fb_prev consumed
+                    QD_STAMP_AT(3);
+                    half = 1;
+                    rt_touch += rt_pf;
+                    continue;
+                }
+                half = 0;
+            }
             if (dyn && tid == 0) {
                 const uint64_t t2 = claim_resolve(claim);
                 wq[0] = (uint32_t)t2; wq[1] = (uint32_t)(t2 >> 32);
@@ -2069,7 +2103,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         tg = tg_next;
     }
     if constexpr (kDefer) {
-        constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct, FL = GeoT::kPackedTile ? GW / 2 : GW;
+        constexpr uint32_t GW = GeoT::G_ct * GeoT::W_ct, GWP = kHalf ? GeoT::kHalfOut : GW, FL = GeoT::kPackedTile ? GWP / 2 : GWP;
         if (kQuadFft && P.epi != 2) {
             if (dprev_valid && (tid >> 6) >= FL / 64 && (tid >> 6) < FL / 64 + 4) quad_fft_epilogue(fb0 + (size_t)(dpar ^ 1u) * GW, dprev_w0, (tid >> 6) - FL / 64);
         } else
@@ -2182,32 +2216,21 @@ __global__ __launch_bounds__(NT, LB) void k_chain_pipe(const ChainParams P) {
     auto claim_resolve = [&](unsigned long long got) -> uint64_t {
         uint32_t mx = my_x;
         asm volatile("" : "+s"(mx));
-        if (got < xcd_limit(mx)) return (uint64_t)mx * n8 + got;
+        const uint64_t dyn_base = 2 * walk_step;
+        if (got + dyn_base < xcd_limit(mx)) return (uint64_t)mx * n8 + dyn_base + got;
 #pragma unroll 1
-        for (uint32_t k = 1; k < 8; ++k) {
+        for (uint32_t k = 1; k < 8; ++k) {                                // own eighth exhausted: help the others
             const uint32_t xx = (mx + k) & 7u;
             const uint64_t lim = xcd_limit(xx);
-            if (lim == 0) continue;
+            if (lim <= dyn_base) continue;
             const unsigned long long i = atomicAdd(&P.work[16 * xx], 1ull);
-            if (i < lim) return (uint64_t)xx * n8 + i;
+            if (i + dyn_base < lim) return (uint64_t)xx * n8 + dyn_base + i;
         }
         return n_tiles;
     };
     uint64_t tile, tile_n;
-    if (dyn) {
-        if (tid == 0) {
-            const uint64_t a = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
-            const uint64_t b = claim_resolve(atomicAdd(&P.work[16 * my_x], 1ull));
-            wq[0] = (uint32_t)a; wq[1] = (uint32_t)(a >> 32); wq[2] = (uint32_t)b; wq[3] = (uint32_t)(b >> 32);
-        }
-        __syncthreads();
-        tile = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
-        tile_n = ((uint64_t)__builtin_amdgcn_readfirstlane(wq[3]) << 32) | __builtin_amdgcn_readfirstlane(wq[2]);
-        __syncthreads();
-    } else {
-        tile = walk_tile(walk_local);
-        tile_n = walk_tile(walk_local + walk_step);
-    }
+    tile = walk_tile(walk_local);                                         // static for the first two rounds, dynamic or static after
+    tile_n = walk_tile(walk_local + walk_step);
 
     // ---- producer state
     LaneRot lr[SPL];

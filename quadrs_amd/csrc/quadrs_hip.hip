@@ -308,8 +308,10 @@ chain_fn pick_generic(int fmt, int nco, bool fir, bool aligned) {
 // Same source as the generic kernel with W,S,D,T,G as compile-time constants.
 const FixedEntry kFixed[] = {
     // configs[1]  "shift 280000 | lowpass -power 20 -decimate 16 2000000 | sparkfft -width 128"   (README.md:57-63)
-    QD_FIXED(0, 1, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
-    QD_FIXED(0, 2, 128, 128, 16, 40, 2, 9, true, 4, "cfg2"),
+    // round 3: row-aligned phase 1 (bit 3) WITH non-temporal stream loads (bit 8): 0.232 -> 0.212 ms on one box, 0.233 -> 0.227 on another
+    // (profiles/r03/sweep_cfg2_nt.log; round 2 measured the row-aligned phase 1 alone 1.5 % slower, and it still is without nt)
+    QD_FIXED_FB(0, 1, 128, 128, 16, 40, 2, 9, true, 4, 1, 1, 264, "cfg2"),
+    QD_FIXED_FB(0, 2, 128, 128, 16, 40, 2, 9, true, 4, 1, 1, 264, "cfg2"),
     // north_star target sentence: 200-tap FIR decimate 32 -> 128-pt FFT
     // packed lane-per-output FIR on a 16-byte-row tile (FixedGeo FLAGS_ bit 2, PAD 2): half the VALU instructions of the FIR
     // + row-aligned fast phase 1 (bit 3): buffer loads with a per-tile descriptor, compile-time row offsets
@@ -325,8 +327,12 @@ const FixedEntry kFixed[] = {
     // snapshots (no helper wave): 37.1 -> 24.9 ms
     // + FLAGS 64 with two FFT slots: the previous window's FFT + epilogue on four of the eight waves the FIR leaves idle -> 23.9 ms
     // + FLAGS 8: row-aligned phase 1 (a window is four rows of 2048 samples + 512) -> 23.3 ms
-    { 0, 0, 1024, 1024, 8, 512, 1, 4, 1024, 2, 2, 200, 5, true, 4, 2,
-      qd::k_chain<0, 0, qd::FixedGeo<1024, 1024, 8, 512, 1, 4, 2, 2, 2, 200>, true, 5, true, true, 4, 1024>, "cfg4" },
+    // round 3, FLAGS 8192: HALF-window tiles — the raw buffer holds the input of 512 outputs, a window is filtered in two passes into
+    // one FFT slot; 512 threads (4 FIR waves + the four-wave deferred FFT), 74 KiB, so TWO workgroups share a CU and one's phase 1 +
+    // barriers (8 k of its 29 k cycles per window) run under the other's FIR: 23.1 -> 22.0 ms, now at the package power cap too
+    // (1390 W; the clock went from 2.32 to 2.19 GHz — profiles/r03/sweep_cfg4_half.log)
+    { 0, 0, 1024, 1024, 8, 512, 1, 4, 512, 2, 2, 8392, 5, true, 4, 2,
+      qd::k_chain<0, 0, qd::FixedGeo<1024, 1024, 8, 512, 1, 4, 2, 2, 2, 8392>, true, 5, true, true, 4, 512>, "cfg4" },
 };
 
 const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t D, uint32_t T) {
@@ -522,21 +528,31 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
 
 struct Geometry {
     uint32_t G = 1, Dp = 1, lds_raw_elems = 0;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0;        // dynamic LDS that fits the main kernel AND the generic kernels (the unaligned-tail launch)
+    size_t lds_main = 0;         // the main kernel's own need when it is smaller (half-window tiles): its launch size, and what bounds workgroups per CU
 };
 
 // Dynamic LDS of a chain kernel with this tiling.  Layout (qd_chain.h, k_chain prologue): raw tile | batch x G*W FFT buffers |
 // twiddles | taps | 8-bit LUT | shared-FIR dec/trc | batch bookkeeping.  The generic kernels (interleaved tile, pad 1, batch 1,
 // taps in LDS) run inside the same allocation for the unaligned slab tail, so the size is the larger of the two layouts.
 size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems, uint32_t pad_per_row = 1, uint32_t batch = 1,
-               bool lut8 = true, uint32_t flags = 0) {
-    const uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
+               bool lut8 = true, uint32_t flags = 0, size_t *main_only = nullptr) {
+    uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
+    const uint64_t full_raw = tile_raw;
+    if ((flags & kGeoHalfTile) && G == 1 && T > 0 && S >= W) tile_raw = (T - T / 2) + (W / 2 - 1) * D + T;     // FixedGeo::kHalfRaw
     auto interleaved = [&](uint32_t padv) {
         const uint64_t pad = (D % 2 == 0) ? padv * (tile_raw / D + 1) : 0;
         uint64_t elems = tile_raw + pad + 1;
         const uint64_t min_elems = (uint64_t)G * W / 2 + 1;     // bucket epilogue parks G*W f32 norms here
         if (elems < min_elems) elems = min_elems;
         return (elems + 1) & ~1ull;                             // keep fb 16-byte aligned
+    };
+    auto gen_elems_of = [&](uint64_t raw) {                       // the runtime-geometry kernels' tile: pad 1, always the full tile
+        const uint64_t pad = (D % 2 == 0) ? (raw / D + 1) : 0;
+        uint64_t elems = raw + pad + 1;
+        const uint64_t min_elems = (uint64_t)G * W / 2 + 1;
+        if (elems < min_elems) elems = min_elems;
+        return (elems + 1) & ~1ull;
     };
     const uint64_t shared_fir = (T && S < W) ? 2 * ((uint64_t)(G - 1) * S + W) * 8 : 0;   // dec[] + trc[] of the shared-FIR mode
     const uint64_t taps_b = ((T + 3) & ~3ull) * 4, lut_b = lut8 ? 256 * 4 : 0;
@@ -546,10 +562,11 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     const bool planar = (flags & kGeoPlanar) && tile_raw < (1u << 24);
     if (planar) { const uint64_t pe = ct_plane_floats((uint32_t)W, (uint32_t)S, (uint32_t)D, (uint32_t)T, G); if (pe > elems) elems = pe; }
     // *raw_elems is what the runtime-geometry kernels read (ChainParams::lds_raw_elems): THEIR raw tile, whatever the main kernel's
-    if (raw_elems) *raw_elems = (uint32_t)interleaved(1);
+    if (raw_elems) *raw_elems = (uint32_t)gen_elems_of(full_raw);
     const bool baked = planar && (flags & kGeoBakedTaps);
     const uint64_t main_b = elems * 8 + (uint64_t)batch * G * W * 8 + W * 8 + (baked ? 0 : taps_b) + lut_b + shared_fir + (uint64_t)batch * 16 + 16;
-    const uint64_t generic_b = interleaved(1) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16 + 16;
+    const uint64_t generic_b = gen_elems_of(full_raw) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16 + 16;
+    if (main_only) *main_only = (size_t)main_b;       // what the MAIN kernel needs (half-window tiles: well under the generic kernels' full tile)
     return (size_t)(main_b > generic_b ? main_b : generic_b);
 }
 
@@ -682,7 +699,9 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     int rc = QD_OK;
     if (tabs->launched && tabs->last_stream != st) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));      // see NcoTabs
     if (p->has_shift) {
-        rc = ensure_rowtab_for(p, p->nt * spl_of(fmt), &tabs->main, need0, need1, st);
+        // row-aligned phase 1: rows of a short last tile's missing windows (and a half-window pass's read-ahead) get table entries too
+        const uint64_t extra = ((p->kflags & kGeoFastP1) && (p->jit_fn || p->fixed)) ? (uint64_t)p->geo.G * p->S * p->D + p->T : 0;
+        rc = ensure_rowtab_for(p, p->nt * spl_of(fmt), &tabs->main, need0, need1 + extra, st);
         if (rc) return rc;
     }
 
@@ -735,8 +754,10 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         const uint64_t usable = (src_count / spl) * spl + src_first;     // end of the last whole vector
         n_aligned = n_windows;
         while (n_aligned > 0 && (first_window + n_aligned - 1) * step + rpw > usable) --n_aligned;
-        // the fast phase 1 (FixedGeo FLAGS_ bit 3) takes whole tiles only: a short last tile goes to the per-sample kernel
-        if ((p->kflags & kGeoFastP1) && (p->jit_fn || p->fixed)) n_aligned -= n_aligned % p->geo.G;
+        // The fast phase 1 (FixedGeo FLAGS_ bit 3) loads and parks a compile-time number of rows per tile, whatever the tile's
+        // window count: a short LAST tile (n_windows not a multiple of G) costs it a few rows nobody reads — the buffer
+        // descriptor's range check covers the slab end, the row table is extended below — instead of a second launch of the
+        // per-sample kernel for one window (cfg2: 65 535 windows in tiles of two; ~8 us of a 0.21 ms step).
     }
     const bool tail_tables = n_aligned < n_windows && p->nt != kThreads && p->has_shift;
     if (tail_tables) {
@@ -762,9 +783,9 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         if (part == 0 && (grid & 7u) == 0 && n_tiles >= 4ull * grid) { rc = ensure_work(tabs); if (rc) return rc; P.work = tabs->work; }
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
             void *args[] = {&P};
-            HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->launch_nt, 1, 1, (unsigned)p->geo.lds_bytes, st, args, nullptr));
+            HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->launch_nt, 1, 1, (unsigned)(p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes), st, args, nullptr));
         } else {
-            hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->launch_nt : kThreads), p->geo.lds_bytes, st, P);
+            hipLaunchKernelGGL(part == 0 ? p->fn : p->fn_unaligned, dim3(grid), dim3(part == 0 ? p->launch_nt : kThreads), part == 0 && p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes, st, P);
             HIPCHK(hipGetLastError());
         }
     }
@@ -917,7 +938,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 8191 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 16383 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -935,7 +956,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (p->has_fir) { p->taps_h.resize(p->T); design_taps(d.lowpass_hz, d.sample_rate, p->T, p->taps_h.data()); }
     auto make_key = [&](uint32_t g, int nt, int lb, int noslp, uint32_t padv, uint32_t batchv = 1, uint32_t flagsv = 0) {
         const uint64_t ROW = (uint64_t)nt * spl_of(d.format);
-        const uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
+        uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
+        if ((flagsv & kGeoHalfTile) && g == 1 && p->S >= p->W) tile_raw = (p->T - p->T / 2) + (uint64_t)(p->W / 2 - 1) * p->D + p->T;      // rows of ONE pass
         // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
         const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
         if (flagsv & kGeoUnrolledFir) noslp = 1;       // its scalar accumulate chains must stay scalar
@@ -967,8 +989,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         if (tile2_geo && W >= 512 && (uint64_t)T >= 4ull * D) {
             // one long window per tile (cfg4's recipe): two outputs per lane as straight-line packed code with in-chain
             // snapshots, the previous window's FFT + epilogue on idle waves, as many threads as the FIR has lanes for
-            const int nt = W >= 1024 ? 1024 : 512;
-            const uint32_t fl = kGeoPackedTile | kGeoDeferFft | (rows_aligned(nt, 1) ? (kGeoFastP1 | kGeoNtLoads) : 0u);
+            // half-window tiles (two passes per window, two workgroups per CU) where a pass is a whole number of rows of 512 threads
+            const uint64_t half_raw = (uint64_t)c_half + (uint64_t)(W / 2 - 1) * D + T, ROW512 = 512ull * spl;
+            const bool half_ok = W >= 1024 && W % 4 == 0 && ((uint64_t)(W / 2) * D) % ROW512 == 0 && ((uint64_t)S * D) % ROW512 == 0 &&
+                                 (half_raw + ROW512 - 1) / ROW512 <= 10 && D % spl == 0;
+            const int nt = half_ok ? 512 : (W >= 1024 ? 1024 : 512);
+            const uint32_t fl = kGeoPackedTile | kGeoDeferFft | (half_ok ? (kGeoHalfTile | kGeoFastP1 | kGeoNtLoads) : (rows_aligned(nt, 1) ? (kGeoFastP1 | kGeoNtLoads) : 0u));
             if (lds_for(1, W, S, D, T_lds, nullptr, 2, 2, lut8, fl) <= kLdsMax) {
                 autosel.valid = true; autosel.G = 1; autosel.nt = nt; autosel.batch = 2; autosel.flags = fl; autosel.firr = 2; autosel.firb = 4;
             }
@@ -1023,7 +1049,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->geo.G = G;
     p->kflags = kflags;
     p->launch_nt = p->nt + ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0);
-    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
+    if (!(kflags & kGeoHalfTile)) p->geo.lds_main = p->geo.lds_bytes;
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
@@ -1047,6 +1074,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
                 p->nt = kThreads; jit_lb = 4; pad = 1; batch = 1; kflags = 0; tune[2] = 1; tune[3] = 8; auto_variant = false;
                 p->geo.G = G; p->kflags = 0; p->launch_nt = kThreads;
                 p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &re2, 1, 1, lut8, 0);
+                p->geo.lds_main = p->geo.lds_bytes;
                 p->geo.lds_raw_elems = re2;
                 p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, 0, 1, 1, 0), &p->jit_note, may_compile, &p->taps_h);
             }
@@ -1066,7 +1094,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->n_cu = prop.multiProcessorCount;
-    int by_lds = (int)(kLdsMax / p->geo.lds_bytes);
+    int by_lds = (int)(kLdsMax / (p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes));
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->launch_nt > kThreads) { int by_threads = 2048 / p->launch_nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
@@ -1250,7 +1278,7 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->ratio = p->ratio;
     info->tile_windows = p->geo.G;
     info->threads = (uint32_t)p->launch_nt;
-    info->lds_bytes = (uint32_t)p->geo.lds_bytes;
+    info->lds_bytes = (uint32_t)(p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes);
     info->kernel_kind = p->jit_fn ? 2u : (p->fixed ? 1u : 0u);
     info->kernel_flags = (p->jit_fn || p->fixed) ? p->kflags : 0u;
     info->_reserved = 0;
@@ -1619,6 +1647,7 @@ int cached_fft_plan(uint64_t W, uint64_t S, int kind, std::shared_ptr<CachedPlan
         p->geo.G = 1;
         uint32_t raw_elems = 0;
         p->geo.lds_bytes = lds_for(1, p->W, p->S, p->D, p->T, &raw_elems, 1, 1, false);
+        p->geo.lds_main = p->geo.lds_bytes;
         p->geo.lds_raw_elems = raw_elems;
         p->fn = p->fn_unaligned;
     }

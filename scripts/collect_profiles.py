@@ -20,6 +20,23 @@ for f in sorted(os.listdir(src)):
     if f.endswith(".json"):
         d = json.load(open(os.path.join(src, f)))
         wl = d["workload"]
+        # the traffic figure may only describe the kernel bench.py times for this workload: the bench line of the same box
+        # (config.kernel_flags, baked-taps bit excluded: it does not change the memory traffic) against the profiled kernel's name
+        bline = os.path.join(src, f"{rnd}_bench_{'default' if wl == 'cfg3p' else wl}.json")
+        ident = d.get("kernel_identity")
+        if os.path.exists(bline) and ident is not None:
+            try:
+                bj = json.loads(open(bline).read().strip().splitlines()[-1])
+                bflags = bj["config"].get("kernel_flags")
+                if bj["config"]["workload"].split(":")[0] == wl and bflags is not None and (bflags & ~2) != (ident["flags"] & ~2):
+                    print(f"REFUSED {wl}: profiled kernel flags {ident['flags']} != bench kernel flags {bflags}: traffic not published", file=sys.stderr)
+                    continue
+            except Exception as e:
+                print(f"{wl}: cannot compare the profiled kernel with the bench line ({e}): traffic not published", file=sys.stderr)
+                continue
+        elif ident is None:
+            print(f"{wl}: summary carries no kernel identity: traffic not published", file=sys.stderr)
+            continue
         calibrated = True                                     # 16 and 8 B per lane both calibrated (see the docstring)
         traffic["workloads"][wl] = {
             "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch") if calibrated else None,

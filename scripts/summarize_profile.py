@@ -10,13 +10,16 @@ res = {"tag": tag, "workload": workload, "bench_args": args}
 ks = glob.glob(f"{out}/kt/*/*kernel_stats.csv")
 rows = list(csv.DictReader(open(ks[0])))
 chain = [r for r in rows if "k_chain" in r["Name"]]
+# a run may launch a second, tiny chain kernel for windows at an unaligned slab end: the profiled kernel is the one with the most time
+chain.sort(key=lambda r: -float(r["AverageNs"]) * float(r["Calls"]))
+main_name = chain[0]["Name"] if chain else ""
 res["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in chain]
 # kernel_stats.csv averages every launch of the process, including bench.py's settle phase (isolated launches, each
 # followed by a synchronize, run a few % faster than back-to-back ones).  The timed region is the last 40 launches of
 # the kernel trace: their durations are what bench.py's roofline.kernel_ms must agree with.
 kt = glob.glob(f"{out}/kt/*/*kernel_trace.csv")
 if kt:
-    tr = [r for r in csv.DictReader(open(kt[0])) if "k_chain" in r["Kernel_Name"]]
+    tr = [r for r in csv.DictReader(open(kt[0])) if r["Kernel_Name"] == main_name]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
     tr = tr[-40:]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
@@ -30,11 +33,18 @@ for d in ("fetch", "write", "sq", "sq2"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "k_chain" in r["Kernel_Name"]:
+        if r["Kernel_Name"] == main_name:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pmc[k] = sum(v) / len(v)
 res["pmc_mean_per_launch"] = pmc
+# which kernel this is: the FixedGeo template arguments of the profiled kernel's name (W, S, D, T, G, FIRB, FIRR, PAD, BATCH, FLAGS) —
+# scripts/collect_profiles.py refuses to publish traffic for a kernel other than the one bench.py reports for the workload
+import re
+m = re.search(r"FixedGeo<([0-9u, ]+)>", chain[0]["Name"]) if chain else None
+if m:
+    geo = [int(v.strip().rstrip("u")) for v in m.group(1).split(",")]
+    res["kernel_identity"] = {"geo": geo, "flags": geo[9] if len(geo) > 9 else 0, "pipe": "k_chain_pipe" in chain[0]["Name"]}
 # MI355X_MICROARCH.md §HBM: FETCH_SIZE (KiB) reports exactly half of a 16 B/lane streaming read on gfx950
 # -> double it; WRITE_SIZE (KiB) is exact for 16 B/lane... our 4 B/lane output stores are a small term.
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:

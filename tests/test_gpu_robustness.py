@@ -246,6 +246,13 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (0, (200_000, 32, 200), 128, 128, 280_000, (1, 256, 1, 8, 6, 2, 2 | (1540 << 8), 0)),
     (0, (2_000_000, 16, 40), 128, 128, 280_000, (1, 256, 1, 8, 6, 2, 2 | (1796 << 8), 0)),    # cfg2's shape: rows 0-1 / 2 / 3-4, nt loads
     (1, (2_000_000, 16, 40), 128, 128, None, (1, 256, 1, 8, 5, 2, 1 | (516 << 8), 0)),        # cs8 rows of 1024 samples, no shift
+    # the built-in cfg2 set (row-aligned phase 1 + nt loads, two windows per tile): 39 windows = a SHORT last tile through the fast path
+    (0, (2_000_000, 16, 40), 128, 128, 280_000, (2, 256, 1, 8, 4, 1, 1 | (264 << 8), 0)),
+    # half-window tiles (bit 13): two passes per window into one FFT slot, two workgroups per CU — cfg4's shape, and a 256-point
+    # window through the packed lane-per-output FIR with a shift stage
+    (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 512, 2, 4, 4, 2, 2 | (8392 << 8), 0)),
+    (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 512, 2, 4, 4, 2, 2 | (8648 << 8), 0)),
+    (0, (200_000, 32, 200), 256, 256, 280_000, (1, 256, 1, 8, 4, 2, 2 | (8268 << 8), 0)),
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift, hint, epi):
@@ -304,7 +311,7 @@ def test_unhinted_plans_select_the_fast_variants(engine, oracle):
     p = Q.Plan(0, 21_000_000, 1 << 22, shift_hz=280000, lowpass=(200_000, 32, 192), width=128, kernel_policy=Q.KERNEL_SPECIALISE)
     assert p.info.kernel_kind == 2 and p.info.kernel_flags == (4 | 8 | 64 | 256) and p.info.threads == 256, (p.info.kernel_kind, p.info.kernel_flags)
     p = Q.Plan(0, 100_000_000, 1 << 24, lowpass=(5_000_000, 8, 384), width=1024, kernel_policy=Q.KERNEL_SPECIALISE)
-    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (128 | 64 | 8 | 256) and p.info.threads == 1024, (p.info.kernel_kind, p.info.kernel_flags)
+    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (128 | 64 | 8 | 256 | 8192) and p.info.threads == 512, (p.info.kernel_kind, p.info.kernel_flags)      # half-window tiles
     # the policy is not consulted for chains the generic policy must keep: overlapping windows, tiny filters
     p = Q.Plan(0, 21_000_000, 1 << 22, lowpass=(2_000_000, 16, 24), width=128, kernel_policy=Q.KERNEL_SPECIALISE)
     assert p.info.kernel_flags == 0
