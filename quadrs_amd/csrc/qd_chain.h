@@ -1308,7 +1308,9 @@ constexpr bool fast_p1_ok(int rch, bool whole, bool aligned) {
         constexpr uint32_t ROW = NT * FmtTraits<FMT>::SPL;
         constexpr uint32_t tile_raw = GeoT::kHalfTile ? GeoT::kHalfRaw : (GeoT::G - 1) * GeoT::S * GeoT::D + GeoT::W * GeoT::D + GeoT::T;
         constexpr uint32_t step = GeoT::kHalfTile ? GeoT::kHalfOut * GeoT::D : GeoT::S * GeoT::D;      // raw samples between consecutive passes
-        return whole && aligned && step % ROW == 0 && (GeoT::S * GeoT::D) % ROW == 0 && (uint32_t)rch == (tile_raw + ROW - 1) / ROW && GeoT::D % FmtTraits<FMT>::SPL == 0 &&
+        // tiles start at (first_window + t G) S D: on a row boundary for every t when G S D is a multiple of the row AND the launch's
+        // first window is (the host checks that per launch and sends a misaligned range to the per-sample kernel)
+        return whole && aligned && step % ROW == 0 && (GeoT::G * GeoT::S * GeoT::D) % ROW == 0 && (uint32_t)rch == (tile_raw + ROW - 1) / ROW && GeoT::D % FmtTraits<FMT>::SPL == 0 &&
                (GeoT::kFlags & kGeoFastP1);
     }
 }

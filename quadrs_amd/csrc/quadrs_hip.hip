@@ -748,7 +748,9 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     const bool vec_ok = (reinterpret_cast<uintptr_t>(src_d) % vec_bytes) == 0 && (src_first % spl) == 0 &&
                         src_count * (uint64_t)bps >= (uint64_t)vec_bytes;
     uint64_t n_aligned = 0;
-    if (vec_ok) {
+    // row-aligned phase 1 with G S D (not S D) a multiple of the row: the launch's first window must sit on a row boundary too
+    const bool fast_misaligned = (p->kflags & kGeoFastP1) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
+    if (vec_ok && !fast_misaligned) {
         // windows [first_window, first_window + n_aligned): need-end rounded up to a vector fits in the slab
         const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
         const uint64_t usable = (src_count / spl) * spl + src_first;     // end of the last whole vector
@@ -959,7 +961,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
         if ((flagsv & kGeoHalfTile) && g == 1 && p->S >= p->W) tile_raw = (p->T - p->T / 2) + (uint64_t)(p->W / 2 - 1) * p->D + p->T;      // rows of ONE pass
         // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
-        const uint64_t rows = (tile_raw + ROW - 1) / ROW + ((((uint64_t)p->S * p->D) % ROW) ? 1 : 0);
+        const bool tiles_on_rows = (((uint64_t)p->S * p->D) % ROW) == 0 || ((flagsv & kGeoFastP1) && (((uint64_t)g * p->S * p->D) % ROW) == 0);
+        const uint64_t rows = (tile_raw + ROW - 1) / ROW + (tiles_on_rows ? 0 : 1);
         if (flagsv & kGeoUnrolledFir) noslp = 1;       // its scalar accumulate chains must stay scalar
         return JitKey{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, lb, nt,
                       p->W, p->S, p->D, p->T, g, tune[3], tune[2], noslp, padv, batchv, flagsv,

@@ -253,6 +253,8 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 512, 2, 4, 4, 2, 2 | (8392 << 8), 0)),
     (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 512, 2, 4, 4, 2, 2 | (8648 << 8), 0)),
     (0, (200_000, 32, 200), 256, 256, 280_000, (1, 256, 1, 8, 4, 2, 2 | (8268 << 8), 0)),
+    # row-aligned phase 1 where only G*S*D (not S*D) is a multiple of the row: cs8, 24 windows of stride 16 per tile (3 rows of 4096)
+    (1, (200_000, 32, 400), 64, 16, 280_000, (24, 1024, 1, 8, 4, 2, 1 | (40 << 8), 0)),
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift, hint, epi):
@@ -278,6 +280,9 @@ def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift
     a, b = ref_plan.run_host(data), var_plan.run_host(data)
     assert a.shape == b.shape and a.shape[0] in (38, 39)         # bucket: lim / stride windows (src/fft.rs:86), one fewer than sparkfft counts here
     assert a.tobytes() == b.tobytes(), (np.nonzero((a != b).reshape(a.shape[0], -1).any(axis=1))[0][:8],)
+    # a window sub-range that starts inside a tile (and off the row grid of the row-aligned variants)
+    sub = var_plan.run_host(data, 5, 20)
+    assert sub.tobytes() == a[5:25].tobytes()
     if epi == 0 and shift is None:
         ref, _ = oracle.Chain.from_bytes(data, fmt, 21_000_000).lowpass(*lp).spark_fft(W, S, max_windows=40)
         assert bits_equal(ref, b[:ref.shape[0]])
