@@ -496,6 +496,50 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
     return res
 
 
+def fast_mode_leg(cfg, device, steps=8):
+    """QD_MODE_FAST on the default workload (SURVEY 8(b) mode{EXACT_ORDER / FAST}; informational, NEVER `value`): the same chain
+    with the FIR's multiply-adds fused (one rounding per tap).  Reported with its deviation from the exact run in ulp of the
+    window maximum over sampled window ranges."""
+    import torch
+    import quadrs_amd as Q
+    n = cfg["n"]
+    slab = synth_slab(torch, cfg["fmt"], 0, n, STREAM_SEED, device)
+    kw = dict(shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
+    fast = Q.Plan(cfg["fmt"], cfg["sr"], n, mode=Q.MODE_FAST, **kw)
+    exact = Q.Plan(cfg["fmt"], cfg["sr"], n, **kw)
+    a = torch.empty(fast.n_windows, cfg["W"], dtype=torch.float32, device=device)
+    for _ in range(3):
+        fast.run_device(slab, a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fast.run_device(slab, a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    dev_max = 0.0
+    k = min(16384, fast.n_windows)
+    for w0 in (0, (fast.n_windows - k) // 2, fast.n_windows - k):
+        b = torch.empty(k, cfg["W"], dtype=torch.float32, device=device)
+        first, count = exact.src_range(w0, k)
+        exact.run_device(slab.view(torch.uint8).reshape(-1)[first * BPS[cfg["fmt"]]:(first + count) * BPS[cfg["fmt"]]], b, w0, k, src_first=first, src_count=count)
+        torch.cuda.synchronize()
+        aa, bb = a[w0:w0 + k].double(), b.double()
+        mx = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+        ulp = torch.pow(2.0, torch.floor(torch.log2(mx.double())) - 23)
+        dev_max = max(dev_max, float(((aa - bb).abs() / ulp).max().item()))
+    alg = n * BPS[cfg["fmt"]] + fast.n_windows * cfg["W"] * 4
+    res = {"mode": "QD_MODE_FAST: FIR multiply-adds fused (v_pk_fma_f32), everything else as in the exact mode; not the reference's bits",
+           "kernel_flags": int(fast.info.kernel_flags), "fused": bool(fast.info.kernel_flags & 16384), "ms_per_step": ms, "steps": steps,
+           "value": fast.n_windows * fast.info.raw_step / (ms * 1e-3) / 1e6, "unit": "Msamples/s", "hbm_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "max_deviation_from_exact_ulp_of_window_max": dev_max}
+    fast.close(); exact.close()
+    del slab, a
+    torch.cuda.empty_cache()
+    return res
+
+
 def end_to_end_host(device):
     """Host-resident cfg2 (1 GiB cf32 in host memory -> norms in host memory) through qd_plan_run's chunked, double-buffered
     path: PCIe-inclusive, reported beside the kernel figures, never as `value`.  Pinned buffers (QD_MEM_HOST_PINNED) are the
@@ -664,6 +708,11 @@ def main():
                 line[k] = main_res[k]
         if others:
             line["others"] = others
+        if world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_others:
+            try:
+                line["fast_mode"] = fast_mode_leg(cfg, device)
+            except Exception as e:                       # informational leg: never takes the bench line down
+                line["fast_mode"] = {"error": str(e)[:200]}
         if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
             try:
                 line["end_to_end"] = end_to_end_host(device)

@@ -133,7 +133,17 @@ typedef struct {
     int32_t  epilogue;        /* qd_epilogue */
     int32_t  has_range;       /* sparkfft -range min:max; else 0.08 / 1.0 (src/fft.rs:22-23) */
     float    range_min, range_max;
+    int32_t  mode;            /* qd_mode: QD_MODE_EXACT (0, the default: the reference's products, order and roundings) or QD_MODE_FAST */
+    int32_t  _pad2;
 } qd_chain_desc;
+
+/* QD_MODE_FAST is a PERMISSION, never the default and never what bench.py's `value` is measured in: the FIR may fuse each
+ * multiply with its add (v_pk_fma_f32: one rounding per tap instead of two, same ascending-tap order), which breaks the
+ * "within 1 ulp of the reference" bound of the exact mode — outputs stay within a few ulp of the window maximum of it and are, if
+ * anything, closer to the infinitely precise filter.  Everything else (unpack, NCO, FFT, |X|) is unchanged.  Kernels without a
+ * fused form (runtime-geometry kernels, overlapping windows, short filters) run the exact arithmetic: qd_plan_info.kernel_flags
+ * bit 14 says whether the plan's kernel fuses. */
+typedef enum { QD_MODE_EXACT = 0, QD_MODE_FAST = 1 } qd_mode;
 
 typedef struct {
     uint64_t n_windows;       /* trip count of the sink's loop: spark_fft `while i < len - W`
@@ -149,7 +159,7 @@ typedef struct {
     uint32_t lds_bytes;
     uint32_t kernel_kind;     /* 0 generic (runtime geometry), 1 built-in shape-specialised, 2 specialised at plan time (hiprtc) */
     uint32_t kernel_flags;    /* variant bits of the main kernel (0 for the generic kernels): 4 packed lane-per-output FIR, 8 row-aligned
-                                 phase 1, 32 straight-line shared FIR, 64 deferred FFT, 128 packed two-output FIR, 256 non-temporal stream loads, 8192 half-window tiles;
+                                 phase 1, 32 straight-line shared FIR, 64 deferred FFT, 128 packed two-output FIR, 256 non-temporal stream loads, 8192 half-window tiles, 16384 fused FIR (QD_MODE_FAST);
                                  chosen from the chain's geometry at plan time (built-in kernels: the same predicates, fixed at build time) */
     uint32_t _reserved;
 } qd_plan_info;

@@ -9,6 +9,6 @@ missing, importing `quadrs_amd.engine` objects raises.
 from . import _ffi  # noqa: F401
 from .engine import (PinnedBuffer, Plan, options_from_env, plan_options, fft_norm_batch, gen, gen_device, lowpass_block, lowpass_design, shift, shift_ratio,  # noqa: F401
                      take_fft, unpack)
-from ._ffi import (KERNEL_AUTO, KERNEL_GENERIC, KERNEL_NO_PLAN_TIME, KERNEL_SPECIALISE, MEM_DEVICE, MEM_HOST, MEM_HOST_PINNED,  # noqa: F401
+from ._ffi import (MODE_EXACT, MODE_FAST, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_NO_PLAN_TIME, KERNEL_SPECIALISE, MEM_DEVICE, MEM_HOST, MEM_HOST_PINNED,  # noqa: F401
                    EPI_BUCKET2_U8, EPI_CF32_BLOCKS, EPI_GLYPH_U8, EPI_NORMS_F32, FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8,  # noqa: F401
                    QuadrsError)

@@ -10,6 +10,7 @@ OK, ERR_INVALID, ERR_PANIC, ERR_SHORT, ERR_HIP, ERR_UNSUPPORTED = range(6)
 FMT_CF32, FMT_CS8, FMT_CU8, FMT_CS16 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALISE, KERNEL_NO_PLAN_TIME = 0, 1, 2, 3
+MODE_EXACT, MODE_FAST = 0, 1
 MAX_SHARDS = 16
 EPI_NORMS_F32, EPI_GLYPH_U8, EPI_BUCKET2_U8, EPI_CF32_BLOCKS = 0, 1, 2, 3
 
@@ -34,6 +35,7 @@ class ChainDesc(C.Structure):
         ("lowpass_hz", C.c_uint64), ("decimate", C.c_uint64), ("taps", C.c_uint64),
         ("width", C.c_uint64), ("stride", C.c_uint64), ("epilogue", C.c_int32),
         ("has_range", C.c_int32), ("range_min", C.c_float), ("range_max", C.c_float),
+        ("mode", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 

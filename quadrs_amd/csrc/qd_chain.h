@@ -141,6 +141,7 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
 constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32,
                    kGeoDeferFft = 64, kGeoPackedTile = 128, kGeoNtLoads = 256;   // FixedGeo FLAGS_ bits
 // cache policy (buffer-load aux operand) of the phase-1 stream loads: bit 8 -> nt, bits 11 / 12 -> sc0 / sc1
+constexpr uint32_t kGeoFastFma = 16384;      // FLAGS_ bit 14: QD_MODE_FAST — the packed FIRs fuse multiply and add (v_pk_fma_f32), one rounding per tap
 constexpr uint32_t kGeoHalfTile = 8192;      // FLAGS_ bit 13: the tile buffer holds HALF a window's FIR input, two passes per window (see FixedGeo::kHalfTile)
 constexpr int ct_load_aux(uint32_t flags) { return ((flags & 256u) ? 2 : 0) | ((flags & 2048u) ? 1 : 0) | ((flags & 4096u) ? 16 : 0); }
 typedef float v2f __attribute__((ext_vector_type(2)));      // operand type of the v_pk_*_f32 instructions
@@ -986,6 +987,15 @@ __device__ __forceinline__ float2 fir_pair(const float2 *rowp /* first LDS row o
             const v2f x0 = {xa[slot].x, xa[slot].y}, x1 = {xa[slot].z, xa[slot].w}, x2 = {xb[slot].x, xb[slot].y}, x3 = {xb[slot].z, xb[slot].w};
             const v2f h01 = {hh[slot].x, hh[slot].y}, h23 = {hh[slot].z, hh[slot].w};
             v2f p0, p1;
+            if constexpr ((GeoT::kFlags & kGeoFastFma) != 0) {
+                // QD_MODE_FAST: acc = fma(x, h, acc) — the same ascending-tap chain with ONE rounding per tap; not the reference's bits
+                asm volatile("v_pk_fma_f32 %0, %1, %5, %0 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                             "v_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                             : "+v"(acc)
+                             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23));
+            } else
             asm volatile("v_pk_mul_f32 %1, %3, %7 op_sel_hi:[1,0]\n\t"
                          "v_pk_mul_f32 %2, %4, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
                          "v_pk_add_f32 %0, %0, %1\n\t"
@@ -1106,6 +1116,18 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
         if (b >= LAG && b < HB) {                                            // both outputs take this block
             const float4 H = hh[b % NS], G = kReTap ? gg[b % PF] : hh[(b - LAG) % NS];
             const v2f h01 = {H.x, H.y}, h23 = {H.z, H.w}, g01 = {G.x, G.y}, g23 = {G.z, G.w};
+            if constexpr ((GeoT::kFlags & kGeoFastFma) != 0) {                // QD_MODE_FAST: fused, two interleaved chains
+                asm volatile("v_pk_fma_f32 %0, %2, %6, %0 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %1, %2, %8, %1 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                             "v_pk_fma_f32 %1, %3, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                             "v_pk_fma_f32 %0, %4, %7, %0 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %1, %4, %9, %1 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %0, %5, %7, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                             "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                             : "+v"(a0), "+v"(a1)
+                             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23), "v"(g01), "v"(g23));
+            } else
             asm volatile("v_pk_mul_f32 %2, %6, %10 op_sel_hi:[1,0]\n\t"
                          "v_pk_mul_f32 %3, %6, %12 op_sel_hi:[1,0]\n\t"
                          "v_pk_mul_f32 %4, %7, %10 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
@@ -1128,6 +1150,14 @@ __device__ __forceinline__ void fir_tiled2_pk(const float2 *lanep, const float *
             const float4 H = b < HB ? hh[b % NS] : (kReTap ? gg[b % PF] : hh[(b - LAG) % NS]);
             const v2f h01 = {H.x, H.y}, h23 = {H.z, H.w};
             v2f &acc = b < HB ? a0 : a1;
+            if constexpr ((GeoT::kFlags & kGeoFastFma) != 0) {
+                asm volatile("v_pk_fma_f32 %0, %1, %5, %0 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                             "v_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[1,0,1]\n\t"
+                             "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                             : "+v"(acc)
+                             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h01), "v"(h23));
+            } else
             asm volatile("v_pk_mul_f32 %1, %3, %7 op_sel_hi:[1,0]\n\t"
                          "v_pk_mul_f32 %2, %4, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
                          "v_pk_add_f32 %0, %0, %1\n\t"

@@ -953,7 +953,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
     const bool jit_ok = d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME;
     // a cached build is always used; a NEW build only when forced or when the stream is at least 1 GiB
-    const bool may_compile = policy == QD_KERNEL_SPECIALISE || tuned || in_bytes >= (1ull << 30);
+    const bool may_compile = policy == QD_KERNEL_SPECIALISE || tuned || in_bytes >= (1ull << 30) || d.mode == QD_MODE_FAST;
     uint32_t batch = 1, kflags = 0;    // tiles per FFT batch / variant flags the main kernel is built with (FixedGeo BATCH_, FLAGS_)
     if (p->has_fir) { p->taps_h.resize(p->T); design_taps(d.lowpass_hz, d.sample_rate, p->T, p->taps_h.data()); }
     auto make_key = [&](uint32_t g, int nt, int lb, int noslp, uint32_t padv, uint32_t batchv = 1, uint32_t flagsv = 0) {
@@ -980,6 +980,11 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // long-filter policy below reached 0.30-0.35).  The predicates restate FixedGeo's own static conditions (qd_chain.h), so the
     // build takes the path asked for; if no variant build is to be had the plan falls back to the plain tiling further down.
     struct { bool valid = false; uint32_t G = 1, batch = 1, flags = 0, firr = 1, firb = 8; int nt = kThreads; } autosel;
+    // QD_MODE_FAST (qd_chain_desc.mode): the built-in kernels are exact-order; a fused build is the geometry recipe + bit 14, made
+    // at plan time whatever the stream's size.  No recipe for the shape (overlapping windows, short filters): the exact kernels.
+    const bool fast_mode = d.mode == QD_MODE_FAST && p->has_fir && jit_ok && !tuned;
+    const FixedEntry *fixed_exact = p->fixed;
+    if (fast_mode) p->fixed = nullptr;
     if (jit_ok && !tuned && !p->fixed && p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && p->S >= p->W) {
         const uint32_t W = p->W, S = p->S, D = p->D, T = p->T, c_half = T - T / 2;
         const int spl = spl_of(d.format);
@@ -1012,6 +1017,10 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
                 autosel.valid = true; autosel.G = g; autosel.nt = 256; autosel.batch = bt; autosel.flags = fl;
             }
         }
+    }
+    if (fast_mode) {
+        if (autosel.valid) autosel.flags |= kGeoFastFma;
+        else p->fixed = fixed_exact;                                   // nothing to fuse in: the exact built-in kernel, if any
     }
     // the long-filter policy serves overlapping windows (shared FIR) and whatever the packed variants above do not take
     bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D && !autosel.valid;
@@ -1194,6 +1203,7 @@ int qd_plan_create_ex(const qd_chain_desc *desc, const qd_plan_options *options,
     const qd_chain_desc &d = *desc;
     if (d.format < 0 || d.format > 3) return fail(QD_ERR_INVALID, "unknown format %d", d.format);
     if (d.epilogue < 0 || d.epilogue > 3) return fail(QD_ERR_INVALID, "unknown epilogue %d", d.epilogue);
+    if (d.mode != QD_MODE_EXACT && d.mode != QD_MODE_FAST) return fail(QD_ERR_INVALID, "unknown mode %d", d.mode);
     if (d.epilogue == QD_EPI_CF32_BLOCKS && !d.has_lowpass) return fail(QD_ERR_INVALID, "QD_EPI_CF32_BLOCKS needs a lowpass in the chain");
     if (!is_pow2(d.width))
         return fail(QD_ERR_PANIC, "Radix4 requires a power-of-two width (rustfft API contract), got %llu", (unsigned long long)d.width);

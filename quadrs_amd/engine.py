@@ -174,7 +174,7 @@ class Plan:
     """The fused chain  from -> [shift] -> [lowpass] -> sparkfft|bucket  (Operation::exec, src/lib.rs:83-175)."""
 
     def __init__(self, fmt, sample_rate, n_samples, shift_hz=None, lowpass=None, width=128, stride=None,
-                 epilogue=_ffi.EPI_NORMS_F32, rng=None, options=None, **option_kw):
+                 epilogue=_ffi.EPI_NORMS_F32, rng=None, options=None, mode=_ffi.MODE_EXACT, **option_kw):
         d = _ffi.ChainDesc()
         d.struct_size = C.sizeof(_ffi.ChainDesc)
         d.format = fmt
@@ -188,6 +188,7 @@ class Plan:
         d.width = width
         d.stride = width if stride is None else stride
         d.epilogue = epilogue
+        d.mode = mode            # MODE_FAST: permission to fuse the FIR's multiply-adds (never the default)
         if rng is not None:
             d.has_range, d.range_min, d.range_max = 1, rng[0], rng[1]
         self.desc = d

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported(engine):
 
 def test_struct_layout(engine):
     from quadrs_amd import _ffi
-    assert C.sizeof(_ffi.ChainDesc) == 104 and C.sizeof(_ffi.PlanInfo) == 80
+    assert C.sizeof(_ffi.ChainDesc) == 112 and C.sizeof(_ffi.PlanInfo) == 80
 
 
 def test_host_arithmetic_matches_oracle(engine, oracle):

@@ -322,6 +322,56 @@ def test_unhinted_plans_select_the_fast_variants(engine, oracle):
     assert p.info.kernel_flags == 0
 
 
+@pytest.mark.parametrize("lp,W,shift,want_flags", [((200_000, 32, 200), 128, 280_000, 4 | 8 | 64 | 256 | 16384),           # the north_star shape
+                                                  ((5_000_000, 8, 512), 1024, None, 128 | 64 | 8 | 256 | 8192 | 16384),  # cfg4's shape
+                                                  ((2_000_000, 16, 40), 128, 280_000, 8 | 256)])                        # a 40-tap filter: nothing to fuse in, the exact built-in kernel
+def test_fast_mode_is_opt_in_and_bounded(engine, oracle, lp, W, shift, want_flags):
+    """QD_MODE_FAST (SURVEY 8(b) `mode{EXACT_ORDER / FAST}`): a permission to fuse the FIR's multiply-adds.  Never the default; the
+    plan says whether its kernel fuses (kernel_flags bit 14); a fused run stays within a few ulp of the window maximum of the exact
+    run, and is no further from the infinitely precise filter (f64 FIR + f64 DFT of the same f32 shifted samples) than the exact
+    run is."""
+    import quadrs_amd as Q
+    from test_gpu_parity import _signal, assert_norms_close, record_observed
+    fc, D, T = lp
+    N = (23 * W + W) * D + T + 5
+    x = _signal(np.random.default_rng(W + T), N).astype(np.float32)
+    data = x.tobytes()
+    exact = Q.Plan(0, 21_000_000, N, shift_hz=shift, lowpass=lp, width=W)
+    fast = Q.Plan(0, 21_000_000, N, shift_hz=shift, lowpass=lp, width=W, mode=Q.MODE_FAST)
+    assert exact.info.kernel_flags & 16384 == 0
+    assert fast.info.kernel_flags == want_flags, (fast.info.kernel_kind, fast.info.kernel_flags)
+    a, b = exact.run_host(data), fast.run_host(data)
+    ref, _ = (oracle.Chain.from_bytes(data, 0, 21_000_000).shift(shift) if shift is not None else oracle.Chain.from_bytes(data, 0, 21_000_000)).lowpass(*lp).spark_fft(W, W)
+    assert_norms_close(ref, a, "exact")
+    if not want_flags & 16384:
+        assert a.tobytes() == b.tobytes()
+        return
+    scale = np.spacing(np.abs(a).max(axis=1, keepdims=True)).astype(np.float64)
+    dev = np.abs(a.astype(np.float64) - b.astype(np.float64)) / scale
+    assert dev.max() <= 8.0, dev.max()
+    assert not np.array_equal(a, b)                              # it IS a different arithmetic
+    # truth for a few windows: f64 FIR over the f32 shifted samples (the Shift stage is f32 by definition), f64 DFT, |X|
+    sh = x.reshape(-1, 2).copy()
+    if shift is not None:
+        sh = oracle.shift_apply(sh, 0, oracle.shift_ratio(shift, 21_000_000))
+    z = sh[:, 0].astype(np.float64) + 1j * sh[:, 1].astype(np.float64)
+    taps = oracle.taps(fc, 21_000_000, T).astype(np.float64)
+    c = T - T // 2
+    err_e = err_f = 0.0
+    for w in (0, 7, 22):
+        dec = np.empty(W, dtype=np.complex128)
+        for k in range(W):
+            jmax = min(T, (W - k) * D + T // 2)
+            s0 = (w * W + k) * D + c
+            dec[k] = np.dot(z[s0:s0 + jmax], taps[:jmax])
+        truth = np.abs(np.fft.fftshift(np.fft.fft(dec)))
+        sc = np.spacing(np.float32(truth.max())).astype(np.float64)
+        err_e = max(err_e, np.abs(a[w] - truth).max() / sc)
+        err_f = max(err_f, np.abs(b[w] - truth).max() / sc)
+    record_observed(f"fast mode W={W} T={T}", fast_vs_exact_ulp=float(dev.max()), exact_vs_truth_ulp=float(err_e), fast_vs_truth_ulp=float(err_f))
+    assert err_f <= err_e + 1.0, (err_e, err_f)
+
+
 def test_plan_time_builds_are_cached_on_disk(tmp_path):
     """A plan-time build lands in $QD_JIT_CACHE; a later process whose stream is far too small to justify a compile
     (auto mode) still gets the specialised kernel from the cache, and the same bits."""
