@@ -2459,4 +2459,266 @@ __global__ __launch_bounds__(NT, LB) void k_chain_pipe(const ChainParams P) {
     if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
 }
 
+// ---------------------------------------------------------------- the three-stage kernel for overlapping windows (FixedGeo FLAGS_ bit 15)
+//
+// Overlapping-window chains with long filters (cfg3, the README's FSK chain: 400 taps, W = 64, S = 16) run k_chain with ONE
+// ~156 KiB tile of 27 windows per CU, so a tile's phases — unpack + NCO, the shared FIR, gather + FFT, |X| — run strictly one
+// after the other and add up (13 k + 12.4 k + 6.4 k stamped cycles): the vector units idle while the FIR
+// waits on LDS, the LDS idles while the NCO computes.  Unlike the 128-point shapes (k_chain_pipe), here a tile's FIR is ONE pass
+// over all of the tile's outputs, and two half-size tiles fit in LDS: so the three stages run CONCURRENTLY on consecutive tiles,
+//     waves 0-7   (512 threads)  phase 1 of tile i+1 into raw[(i+1)&1]   (next tile's rows prefetched in registers)
+//     waves 8-11  (256 lanes)    shared FIR of tile i from raw[i&1] into dec / trc[i&1]   (fir_pair, packed, taps from LDS)
+//     waves 12-15 (4 waves)      tile i-1: gather from dec / trc[(i-1)&1], FFT, |X|, store — each wave its own windows, wave-local
+// with one s_barrier per tile (every wave executes the same number of barriers: nothing to deadlock).  Same products, order and
+// roundings as k_chain's shared-FIR path; the price is the halo of a 12-window tile (31 % of its samples against 14 %).
+constexpr uint32_t kGeoPipe3 = 32768;
+constexpr int kPipe3Threads = 1024, kPipe3Prod = 512;
+
+template <int FMT, class GeoT>
+constexpr bool pipe3_geometry_ok(int rch) {
+    if constexpr (!GeoT::kFixed) return false;
+    else {
+        constexpr uint32_t ROW = (uint32_t)kPipe3Prod * FmtTraits<FMT>::SPL;
+        constexpr uint32_t tile_raw = (GeoT::G - 1) * GeoT::S * GeoT::D + GeoT::W * GeoT::D + GeoT::T;
+        constexpr uint32_t Q = (GeoT::G - 1) * GeoT::S + GeoT::W;
+        return GeoT::kShared && GeoT::kUnrolledShared && Q <= 256 && (GeoT::G * GeoT::S * GeoT::D) % ROW == 0 &&
+               (uint32_t)rch == (tile_raw + ROW - 1) / ROW && GeoT::D % FmtTraits<FMT>::SPL == 0 && GeoT::W <= 64 * 16 && GeoT::G >= 1;
+    }
+}
+// LDS of the three-stage kernel, in float2 elements before the taps (the host restates this: lds_for_pipe3)
+template <class GeoT> constexpr uint32_t pipe3_q_pad() { return (((GeoT::G - 1) * GeoT::S + GeoT::W) + 1) & ~1u; }
+
+template <int FMT, int NCO, class GeoT, int RCH, int LB>
+__global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3(const ChainParams P) {
+    using FT = FmtTraits<FMT>;
+    using Vec = typename FT::Vec;
+    constexpr int SPL = FT::SPL;
+    constexpr bool HAS_SHIFT = NCO != 0;
+    static_assert(pipe3_geometry_ok<FMT, GeoT>(RCH), "three-stage kernel: overlapping windows, straight-line shared FIR, <= 256 outputs per tile, row-aligned tiles");
+    constexpr uint32_t PT = kPipe3Prod;
+    constexpr uint32_t W = GeoT::W, S = GeoT::S, D = GeoT::D, T = GeoT::T, G = GeoT::G, Dp = GeoT::Dp, logW = GeoT::logW;
+    constexpr uint32_t ROW = PT * SPL, ROWB = ROW * FT::BPS, VECB = SPL * FT::BPS;
+    constexpr uint32_t kTileRaw = (G - 1) * S * D + W * D + T, kRem = kTileRaw - (RCH - 1) * ROW;
+    constexpr uint32_t Q = (G - 1) * S + W, QP = pipe3_q_pad<GeoT>();
+    constexpr uint32_t GV = (G + 3) / 4;                                          // windows per FFT wave
+    const GeoT geo(P);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *raw0 = reinterpret_cast<float2 *>(smem);
+    float2 *dec0 = raw0 + 2 * (size_t)geo.lds_raw_elems;                           // dec / trc of set 0, then of set 1
+    float2 *fbx = dec0 + 4 * (size_t)QP;                                           // G*W: the FFT waves' buffers (wave v: windows [v GV, (v+1) GV))
+    float2 *twl = fbx + (size_t)G * W;
+    float *tapl = reinterpret_cast<float *>(twl + W);
+    uint32_t *wq = reinterpret_cast<uint32_t *>(tapl + ((T + 3) & ~3u));
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const uint32_t n_tw = W - geo.base_len;
+        for (uint32_t i = tid; i < n_tw; i += kPipe3Threads) twl[i] = P.tw[i];
+        for (uint32_t i = tid; i < T; i += kPipe3Threads) tapl[i] = P.taps[i];
+    }
+    __syncthreads();
+
+    const uint64_t n_tiles = (P.n_windows + G - 1) / G;
+    uint64_t walk_base = 0, walk_local = blockIdx.x, walk_step = gridDim.x, walk_limit = n_tiles;
+    const bool xcd_walk = (gridDim.x & 7u) == 0 && n_tiles >= 8;
+    const uint64_t n8 = (n_tiles + 7) / 8;
+    auto xcd_limit = [&](uint32_t x) -> uint64_t { const uint64_t b = (uint64_t)x * n8; return b >= n_tiles ? 0 : (n_tiles - b < n8 ? n_tiles - b : n8); };
+    if (xcd_walk) {
+        walk_base = (uint64_t)(blockIdx.x & 7u) * n8;
+        walk_local = blockIdx.x >> 3;
+        walk_step = gridDim.x >> 3;
+        walk_limit = xcd_limit(blockIdx.x & 7u);
+    }
+    auto walk_tile = [&](uint64_t local) -> uint64_t { return local < walk_limit ? walk_base + local : n_tiles; };
+    const bool dyn = P.work != nullptr && xcd_walk;
+    const uint32_t my_x = blockIdx.x & 7u;
+    auto claim_resolve = [&](unsigned long long got) -> uint64_t {                // three static rounds, then the counters
+        uint32_t mx = my_x;
+        asm volatile("" : "+s"(mx));
+        const uint64_t dyn_base = 3 * walk_step;
+        if (got + dyn_base < xcd_limit(mx)) return (uint64_t)mx * n8 + dyn_base + got;
+#pragma unroll 1
+        for (uint32_t k = 1; k < 8; ++k) {
+            const uint32_t xx = (mx + k) & 7u;
+            const uint64_t lim = xcd_limit(xx);
+            if (lim <= dyn_base) continue;
+            const unsigned long long i = atomicAdd(&P.work[16 * xx], 1ull);
+            if (i + dyn_base < lim) return (uint64_t)xx * n8 + dyn_base + i;
+        }
+        return n_tiles;
+    };
+    // the pipeline's tiles: x (FFT stage), f (FIR stage), p (being produced), pn (prefetched next)
+    uint64_t tile_x = n_tiles, tile_f = walk_tile(walk_local), tile_p = walk_tile(walk_local + walk_step), tile_pn = walk_tile(walk_local + 2 * walk_step);
+    walk_local += 2 * walk_step;                                                   // static walk: walk_local names tile_pn's round
+    auto next_after = [&]() -> uint64_t {                                          // the tile after tile_pn, read behind the barrier
+        if (dyn) return ((uint64_t)__builtin_amdgcn_readfirstlane(wq[1]) << 32) | __builtin_amdgcn_readfirstlane(wq[0]);
+        walk_local += walk_step;
+        return walk_tile(walk_local);
+    };
+    auto g_cnt_of = [&](uint64_t t) -> uint32_t {
+        const uint64_t w0 = t * G, left = P.n_windows - w0;
+        return left < G ? (uint32_t)left : G;
+    };
+
+    if (wave < 8) {
+        // ================= producers
+        LaneRot lr[SPL];
+        if constexpr (HAS_SHIFT) {
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                const uint32_t j = tid * SPL + u;
+                const double2 cs = P.jtab[j];
+                lr[u].jf = (double)j; lr[u].c = cs.x; lr[u].s = cs.y;
+            }
+        }
+        const uint32_t lane_pad = pad_index(geo, tid * SPL);
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+        typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+        auto n_start_of = [&](uint64_t t) -> uint64_t { return (P.first_window + t * G) * ((uint64_t)S * D); };
+        auto rsrc_of = [&](uint64_t t) {
+            const uint64_t ns = n_start_of(t);
+            const uint64_t left = (P.src_first + P.src_count - ns) * FT::BPS;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * FT::BPS, 0,
+                                                     left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
+        };
+        Vec pf[RCH];
+        auto load_row = [&](const decltype(rsrc_of(0)) &rsrc, int i) {
+            constexpr uint32_t kLastVec = ((kRem * FT::BPS - 1) / VECB) * VECB;
+            uint32_t voff = tid * VECB;
+            if (i + 1 == RCH && kRem != ROW) voff = voff < kLastVec ? voff : kLastVec;
+            constexpr int aux = ct_load_aux(GeoT::kFlags);
+            if constexpr (sizeof(Vec) == 16) {
+                const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), aux);
+                pf[i].x = w.x; pf[i].y = w.y; pf[i].z = w.z; pf[i].w = w.w;
+            } else {
+                const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), aux);
+                pf[i].x = w.x; pf[i].y = w.y;
+            }
+        };
+        double rt_touch = 0.0;
+        auto produce = [&](uint64_t t_cur, uint64_t t_refill, float2 *rawbuf) {
+            const uint64_t ns = n_start_of(t_cur);
+            const uint64_t t_pf = t_refill < n_tiles ? t_refill : t_cur;          // last tile of this workgroup: harmless re-loads
+            const auto rsrc = rsrc_of(t_pf);
+            const_f64_p rows = (const_f64_p)(uintptr_t)(P.rowtab + (ns / ROW - P.rowtab_row0));
+            if constexpr (HAS_SHIFT) {                                             // L2 touch of the next tile's row bases
+                uint32_t r = tid < (uint32_t)RCH ? tid : (uint32_t)RCH - 1;
+                asm volatile("" : "+v"(r));
+                rt_touch += P.rowtab[n_start_of(t_pf) / ROW - P.rowtab_row0 + r].c;
+            }
+            TileGeo gl{};
+            gl.tile_raw = kTileRaw;
+            RowBase rb_next{};
+            if constexpr (HAS_SHIFT) rb_next = load_rowbase_at(rows, 0);
+#pragma unroll
+            for (int i = 0; i < RCH; ++i) {
+                const Vec v = pf[i];
+                const RowBase rb = rb_next;
+                if constexpr (HAS_SHIFT) { if (i + 1 < RCH) rb_next = load_rowbase_at(rows, i + 1); }
+                if (i + 1 < RCH || kRem == ROW) {
+                    process_row<FMT, PT, NCO, true>(P, geo, gl, i * (int)ROW, tid, v, rb, lr, lane_pad, nullptr, rawbuf);
+                } else {
+                    if (tid * SPL < kRem) process_row<FMT, PT, NCO, (kRem % SPL) == 0>(P, geo, gl, i * (int)ROW, tid, v, rb, lr, lane_pad, nullptr, rawbuf);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_row(rsrc, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_s_setprio(0);
+        uint32_t par = 0;
+        if (tile_f < n_tiles) {
+            const auto rsrc = rsrc_of(tile_f);
+#pragma unroll
+            for (int i = 0; i < RCH; ++i) load_row(rsrc, i);
+            produce(tile_f, tile_p, raw0);
+        }
+        __syncthreads();
+        while (tile_f < n_tiles || tile_x < n_tiles) {
+            if (tile_p < n_tiles) produce(tile_p, tile_pn, raw0 + (size_t)(par ^ 1u) * geo.lds_raw_elems);
+            __syncthreads();
+            const uint64_t nx = next_after();
+            tile_x = tile_f; tile_f = tile_p; tile_p = tile_pn; tile_pn = nx; par ^= 1u;
+        }
+        if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
+    } else if (wave < 12) {
+        // ================= the shared FIR: every decimated output of the tile once, full chain + the truncated snapshot
+        __builtin_amdgcn_s_setprio(2);
+        uint32_t par = 0;
+        constexpr uint32_t c_half = T - T / 2, ntrunc = c_half ? (c_half + D - 1) / D - 1 : 0;
+        __syncthreads();
+        while (tile_f < n_tiles || tile_x < n_tiles) {
+            unsigned long long claim = 0;
+            if (dyn && tid == (uint32_t)kPipe3Prod) claim = atomicAdd(&P.work[16 * my_x], 1ull);     // this wave issues no other vector memory
+            if (tile_f < n_tiles) {
+                const uint32_t g_cnt = g_cnt_of(tile_f);
+                uint32_t qi = tid - (uint32_t)kPipe3Prod;
+                asm volatile("" : "+v"(qi));
+                if (qi < Q) {
+                    uint32_t jmax = T;
+                    if (qi + ntrunc >= W) {                      // may be in the truncated tail of window g
+                        const uint32_t g = (qi - (W - ntrunc)) / S, k = qi - g * S;
+                        if (k < W && g < g_cnt) { const uint32_t jm = (W - k) * D + T / 2; if (jm < T) jmax = jm; }
+                    }
+                    const float2 *rowp = raw0 + (size_t)par * geo.lds_raw_elems + (size_t)(qi + geo.a0) * Dp;
+                    float2 snap = make_float2(0.f, 0.f);
+                    const float2 full = fir_pair<GeoT, true>(rowp, jmax, tapl, &snap);
+                    float2 *dec = dec0 + (size_t)par * 2 * QP, *trc = dec + QP;
+                    dec[qi] = full;
+                    if (jmax < T) trc[qi] = snap;
+                }
+            }
+            if (dyn && tid == (uint32_t)kPipe3Prod) {
+                const uint64_t t2 = claim_resolve(claim);
+                wq[0] = (uint32_t)t2; wq[1] = (uint32_t)(t2 >> 32);
+            }
+            __syncthreads();
+            const uint64_t nx = next_after();
+            tile_x = tile_f; tile_f = tile_p; tile_p = tile_pn; tile_pn = nx; par ^= 1u;
+        }
+    } else {
+        // ================= gather + FFT + |X| of the tile filtered one step earlier: wave v takes windows [v GV, (v+1) GV), all wave-local
+        __builtin_amdgcn_s_setprio(1);
+        uint32_t par = 0;
+        const uint32_t v = wave - 12;
+        __syncthreads();
+        while (tile_f < n_tiles || tile_x < n_tiles) {
+            if (tile_x < n_tiles) {
+                const uint32_t g_cnt = g_cnt_of(tile_x);
+                const uint32_t g0 = v * GV, g1 = (g0 + GV < g_cnt) ? g0 + GV : g_cnt;
+                if (g0 < g1) {
+                    const float2 *dec = dec0 + (size_t)(par ^ 1u) * 2 * QP, *trc = dec + QP;
+                    float2 *fbw = fbx + (size_t)g0 * W;
+                    uint32_t lane = tid & 63u;
+                    asm volatile("" : "+v"(lane));
+                    constexpr uint32_t log_width = 2 * GeoT::layers;
+                    const uint32_t n_o = (g1 - g0) << logW;
+                    for (uint32_t o = lane; o < n_o; o += 64) {
+                        const uint32_t gl_ = o >> logW, k = o & (W - 1);
+                        const uint32_t qi = (g0 + gl_) * S + k;
+                        const bool tr = (W - k) * D + T / 2 < T;
+                        const float2 val = tr ? trc[qi] : dec[qi];
+                        const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                        fbw[(gl_ << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = val;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    wave_fft_epilogue_fn<GeoT>(P, geo, twl, fbw, P.first_window + tile_x * G + g0, g1 - g0, tid);
+                }
+            }
+            __syncthreads();
+            const uint64_t nx = next_after();
+            tile_x = tile_f; tile_f = tile_p; tile_p = tile_pn; tile_pn = nx; par ^= 1u;
+        }
+    }
+    if (dyn && tid == 0) {       // the last workgroup to leave re-arms the queue for the next launch
+        if (atomicAdd(&P.work[16 * 8], 1ull) == (unsigned long long)gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x <= 8; ++x) P.work[16 * x] = 0;
+        }
+    }
+}
+
 }  // namespace qd

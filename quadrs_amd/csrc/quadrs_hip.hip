@@ -418,6 +418,10 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         return nullptr;
     }
     char name[512];
+    if (k.flags & kGeoPipe3)       // the three-stage kernel for overlapping windows (k_chain_pipe3): 512 producer threads + FIR + FFT waves
+        snprintf(name, sizeof name, "qd::k_chain_pipe3<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb);
+    else
     if (k.flags & kGeoPipe)        // the role-split kernel (k_chain_pipe): 256 producer threads + one consumer wave
         snprintf(name, sizeof name, "qd::k_chain_pipe<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d, %d>", k.fmt, k.nco, k.W,
                  k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb, (k.flags & kGeoPipeFftWave) ? 384 : 320);
@@ -566,6 +570,13 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     const bool baked = planar && (flags & kGeoBakedTaps);
     const uint64_t main_b = elems * 8 + (uint64_t)batch * G * W * 8 + W * 8 + (baked ? 0 : taps_b) + lut_b + shared_fir + (uint64_t)batch * 16 + 16;
     const uint64_t generic_b = gen_elems_of(full_raw) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16 + 16;
+    if (flags & kGeoPipe3) {
+        // k_chain_pipe3: two raw tiles | dec + trc of two sets | G*W FFT buffers | twiddles | taps | queue hand-over
+        const uint64_t qp = (((uint64_t)(G - 1) * S + W) + 1) & ~1ull;
+        const uint64_t p3 = 2 * elems * 8 + 4 * qp * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + 64;
+        if (main_only) *main_only = (size_t)p3;
+        return (size_t)(p3 > generic_b ? p3 : generic_b);
+    }
     if (main_only) *main_only = (size_t)main_b;       // what the MAIN kernel needs (half-window tiles: well under the generic kernels' full tile)
     return (size_t)(main_b > generic_b ? main_b : generic_b);
 }
@@ -700,7 +711,7 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     if (tabs->launched && tabs->last_stream != st) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));      // see NcoTabs
     if (p->has_shift) {
         // row-aligned phase 1: rows of a short last tile's missing windows (and a half-window pass's read-ahead) get table entries too
-        const uint64_t extra = ((p->kflags & kGeoFastP1) && (p->jit_fn || p->fixed)) ? (uint64_t)p->geo.G * p->S * p->D + p->T : 0;
+        const uint64_t extra = ((p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed)) ? (uint64_t)p->geo.G * p->S * p->D + p->T : 0;
         rc = ensure_rowtab_for(p, p->nt * spl_of(fmt), &tabs->main, need0, need1 + extra, st);
         if (rc) return rc;
     }
@@ -749,7 +760,7 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
                         src_count * (uint64_t)bps >= (uint64_t)vec_bytes;
     uint64_t n_aligned = 0;
     // row-aligned phase 1 with G S D (not S D) a multiple of the row: the launch's first window must sit on a row boundary too
-    const bool fast_misaligned = (p->kflags & kGeoFastP1) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
+    const bool fast_misaligned = (p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
     if (vec_ok && !fast_misaligned) {
         // windows [first_window, first_window + n_aligned): need-end rounded up to a vector fits in the slab
         const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
@@ -940,7 +951,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 16383 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 65535 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -961,9 +972,9 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         uint64_t tile_raw = (uint64_t)(g - 1) * p->S * p->D + (uint64_t)p->W * p->D + p->T;
         if ((flagsv & kGeoHalfTile) && g == 1 && p->S >= p->W) tile_raw = (p->T - p->T / 2) + (uint64_t)(p->W / 2 - 1) * p->D + p->T;      // rows of ONE pass
         // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
-        const bool tiles_on_rows = (((uint64_t)p->S * p->D) % ROW) == 0 || ((flagsv & kGeoFastP1) && (((uint64_t)g * p->S * p->D) % ROW) == 0);
+        const bool tiles_on_rows = (((uint64_t)p->S * p->D) % ROW) == 0 || ((flagsv & (kGeoFastP1 | kGeoPipe3)) && (((uint64_t)g * p->S * p->D) % ROW) == 0);
         const uint64_t rows = (tile_raw + ROW - 1) / ROW + (tiles_on_rows ? 0 : 1);
-        if (flagsv & kGeoUnrolledFir) noslp = 1;       // its scalar accumulate chains must stay scalar
+        if ((flagsv & kGeoUnrolledFir) && !(flagsv & kGeoPipe3)) noslp = 1;       // its scalar accumulate chains must stay scalar (the three-stage kernel's FIR is the packed asm form)
         return JitKey{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, lb, nt,
                       p->W, p->S, p->D, p->T, g, tune[3], tune[2], noslp, padv, batchv, flagsv,
                       (flagsv & kGeoBakedTaps) ? fnv1a(p->taps_h.data(), p->taps_h.size() * sizeof(float)) : 0ull};
@@ -1060,9 +1071,9 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     }
     p->geo.G = G;
     p->kflags = kflags;
-    p->launch_nt = p->nt + ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0);
+    p->launch_nt = p->nt + ((kflags & kGeoPipe3) ? 512 : ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0));
     p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
-    if (!(kflags & kGeoHalfTile)) p->geo.lds_main = p->geo.lds_bytes;
+    if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");

@@ -255,6 +255,10 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (0, (200_000, 32, 200), 256, 256, 280_000, (1, 256, 1, 8, 4, 2, 2 | (8268 << 8), 0)),
     # row-aligned phase 1 where only G*S*D (not S*D) is a multiple of the row: cs8, 24 windows of stride 16 per tile (3 rows of 4096)
     (1, (200_000, 32, 400), 64, 16, 280_000, (24, 1024, 1, 8, 4, 2, 1 | (40 << 8), 0)),
+    # the three-stage kernel for overlapping windows (k_chain_pipe3, bit 15): producers / shared FIR / FFT waves on consecutive tiles
+    (1, (200_000, 32, 400), 64, 16, 280_000, (12, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0)),     # cfg3's chain: cs8, 12 windows per tile
+    (0, (200_000, 32, 400), 64, 16, 280_000, (12, 512, 1, 8, 4, 2, 1 | (33056 << 8), 0)),     # the README FSK chain: cf32, nt loads
+    (3, (300_000, 16, 128), 64, 32, None, (4, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0)),         # cs16, other taps / stride, no shift (4 windows = one row of 2048)
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift, hint, epi):
@@ -275,7 +279,7 @@ def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift
     var_plan = engine.Plan(fmt, 21_000_000, N, tile_hint=list(hint), **kw)
     assert ref_plan.info.kernel_kind == 0 and var_plan.info.kernel_kind == 2
     flags = hint[6] >> 8
-    threads = hint[1] + (0 if not flags & 512 else (128 if flags & 1024 else 64))       # the role-split kernel adds its consumer wave(s)
+    threads = hint[1] + (512 if flags & 32768 else (0 if not flags & 512 else (128 if flags & 1024 else 64)))       # the role-split kernels add their consumer waves
     assert var_plan.info.tile_windows == hint[0] and var_plan.info.threads == threads
     a, b = ref_plan.run_host(data), var_plan.run_host(data)
     assert a.shape == b.shape and a.shape[0] in (38, 39)         # bucket: lim / stride windows (src/fft.rs:86), one fewer than sparkfft counts here
@@ -594,3 +598,25 @@ def test_take_fft_any_width_against_f64_dft(engine, oracle, fsk, W, out_len):
             worst_ulp = max(worst_ulp, float((err / np.spacing(ref[r]).astype(np.float64)).max()))
             exact += int((got[r].view(np.uint32) == ref[r].view(np.uint32)).sum())
         record_observed(f"take_fft W={W} windowing={windowing}", rows=out_len, worst_ulp=worst_ulp, exact_fraction=exact / (out_len * W))
+
+
+def test_three_stage_kernel_with_the_tile_queue(engine):
+    """k_chain_pipe3 (producers / shared FIR / FFT waves on consecutive tiles) at a size where the dynamic tile queue is active
+    (10 922 tiles on 256 workgroups) and the last tile is short: bit for bit against the generic kernel, run twice."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    n = 1 << 26
+    src = bench.synth_slab(torch, 1, 0, n, 0x5EED0002, dev)
+    kw = dict(shift_hz=280000, lowpass=(200_000, 32, 400), width=64, stride=16)
+    ref = engine.Plan(1, 21_000_000, n, kernel_policy=engine.KERNEL_GENERIC, **kw)
+    var = engine.Plan(1, 21_000_000, n, tile_hint=[12, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0], **kw)
+    assert var.info.kernel_flags == 32800 and var.info.threads == 1024 and ref.n_windows % 12 != 0
+    a = torch.empty(ref.n_windows, 64, dtype=torch.float32, device=dev)
+    b = torch.zeros_like(a)
+    ref.run_device(src, a)
+    for _ in range(2):
+        b.zero_()
+        var.run_device(src, b)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
