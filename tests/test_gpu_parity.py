@@ -394,7 +394,7 @@ def test_full_size_census(engine, oracle, name):
     ~1e-8 f32-ulp of a rounding boundary may round the other way: DESIGN.md section 4), and those within a fraction of an ulp of
     the window maximum.  Observed (profiles/r02/full_census.log, profiles/r03): cfg2, cfg3' and cfg4 identical in every bit; cfg3
     (16.8 M windows, 8.6e9 samples through the NCO, 1.5-3 minutes of host time) all but 8 windows, 0.12 ulp at worst — so the
-    bounds below are 0 windows for the first three and <= 8 windows / 0.2 ulp for cfg3."""
+    bounds below are 0 windows without a shift stage, <= 2 for cfg2 / cfg3' and <= 12 windows / 0.2 ulp for cfg3."""
     import bench
     from oracle import oracle as O
     from util import full_size_census
@@ -404,7 +404,7 @@ def test_full_size_census(engine, oracle, name):
     if bench.WORKLOADS[name]["shift"] is None:
         assert nw == 0, (nw, nb, worst, first)                           # no NCO: every bit
     elif name == "cfg3":
-        assert nw <= 8 and worst <= 0.2, (nw, nb, worst, first)
+        assert nw <= 12 and worst <= 0.2, (nw, nb, worst, first)      # observed: 8 windows on round 2's stream and on round 3's, 0.06-0.12 ulp
     else:
         # 2^27 / 2^31 samples through the NCO: at the observed rate of ~2e-10 rounding-boundary events per sample (cfg3: 2 samples
         # of 8.6e9) the expectation is 0.03 / 0.5 windows.  Round 2's stream had none; round 3's counter-based stream has one in
