@@ -141,6 +141,7 @@ constexpr uint32_t ct_plane_floats(uint32_t W, uint32_t S, uint32_t D, uint32_t 
 constexpr uint32_t kGeoPlanar = 1, kGeoBakedTaps = 2, kGeoNoSplit = 4, kGeoFastP1 = 8, kGeoPackedSpan = 16, kGeoUnrolledFir = 32,
                    kGeoDeferFft = 64, kGeoPackedTile = 128, kGeoNtLoads = 256;   // FixedGeo FLAGS_ bits
 // cache policy (buffer-load aux operand) of the phase-1 stream loads: bit 8 -> nt, bits 11 / 12 -> sc0 / sc1
+constexpr uint32_t kGeoNtInner = 65536;      // FLAGS_ bit 16 (with bit 8): rows a neighbouring tile reads too (the first and the last of a row-aligned tile) keep the default policy
 constexpr uint32_t kGeoFastFma = 16384;      // FLAGS_ bit 14: QD_MODE_FAST — the packed FIRs fuse multiply and add (v_pk_fma_f32), one rounding per tap
 constexpr uint32_t kGeoHalfTile = 8192;      // FLAGS_ bit 13: the tile buffer holds HALF a window's FIR input, two passes per window (see FixedGeo::kHalfTile)
 constexpr int ct_load_aux(uint32_t flags) { return ((flags & 256u) ? 2 : 0) | ((flags & 2048u) ? 1 : 0) | ((flags & 4096u) ? 16 : 0); }
@@ -1629,11 +1630,16 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 constexpr uint32_t kLastVec = ((kRem * FT::BPS - 1) / VECB) * VECB;
                 uint32_t voff = tid * VECB;
                 if (i + 1 == RCH && kRem != NT * SPL) voff = voff < kLastVec ? voff : kLastVec;
+                // the tile's first and last row are read by the neighbouring tile as well (its halo): with bit 16 they keep the default
+                // cache policy and stay L2 hits for the second reader; the rows in between are read once and go non-temporal
+                const bool shared_row = (GeoT::kFlags & kGeoNtInner) && (i == 0 || i + 1 == RCH);
                 if constexpr (sizeof(Vec) == 16) {
-                    const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), ct_load_aux(GeoT::kFlags));
+                    const v4u_t w = shared_row ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), 0)
+                                               : __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), ct_load_aux(GeoT::kFlags));
                     pf[i].x = w.x; pf[i].y = w.y; pf[i].z = w.z; pf[i].w = w.w;
                 } else {
-                    const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), ct_load_aux(GeoT::kFlags));
+                    const v2u_t w = shared_row ? __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), 0)
+                                               : __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), ct_load_aux(GeoT::kFlags));
                     pf[i].x = w.x; pf[i].y = w.y;
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -310,16 +310,19 @@ const FixedEntry kFixed[] = {
     // configs[1]  "shift 280000 | lowpass -power 20 -decimate 16 2000000 | sparkfft -width 128"   (README.md:57-63)
     // round 3: row-aligned phase 1 (bit 3) WITH non-temporal stream loads (bit 8): 0.232 -> 0.212 ms on one box, 0.233 -> 0.227 on another
     // (profiles/r03/sweep_cfg2_nt.log; round 2 measured the row-aligned phase 1 alone 1.5 % slower, and it still is without nt)
-    QD_FIXED_FB(0, 1, 128, 128, 16, 40, 2, 9, true, 4, 1, 1, 264, "cfg2"),
-    QD_FIXED_FB(0, 2, 128, 128, 16, 40, 2, 9, true, 4, 1, 1, 264, "cfg2"),
+    // + bit 16: the tile's first and last row — the ones the neighbouring tile reads as well — keep the default cache policy (L2 hits
+    //   for the second reader), the seven rows in between go non-temporal: 0.200 -> 0.191 ms (profiles/r03/sweep_nt_inner.log)
+    QD_FIXED_FB(0, 1, 128, 128, 16, 40, 2, 9, true, 4, 1, 1, 65800, "cfg2"),
+    QD_FIXED_FB(0, 2, 128, 128, 16, 40, 2, 9, true, 4, 1, 1, 65800, "cfg2"),
     // north_star target sentence: 200-tap FIR decimate 32 -> 128-pt FFT
     // packed lane-per-output FIR on a 16-byte-row tile (FixedGeo FLAGS_ bit 2, PAD 2): half the VALU instructions of the FIR
     // + row-aligned fast phase 1 (bit 3): buffer loads with a per-tile descriptor, compile-time row offsets
     // + deferred FFT (bit 6, two FFT slots): the previous tile's FFT + epilogue on a wave the FIR leaves idle
     // + nt stream loads (bit 8): the slab is read once; the non-temporal policy measured 1.0-1.2 % over the default on three boxes
     //   (profiles/r03/sweep_cfg3p_load_policy.log; sc0 / sc1 on top of it: nothing)
-    QD_FIXED_FB(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 332, "cfg3p"),
-    QD_FIXED_FB(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 332, "cfg3p"),
+    // + bit 16: first and last row of the tile (shared with the neighbouring tiles) at the default policy: another 1.0 %
+    QD_FIXED_FB(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 65868, "cfg3p"),
+    QD_FIXED_FB(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 65868, "cfg3p"),
     // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
@@ -951,7 +954,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 65535 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 131071 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -1013,7 +1016,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             const bool half_ok = W >= 1024 && W % 4 == 0 && ((uint64_t)(W / 2) * D) % ROW512 == 0 && ((uint64_t)S * D) % ROW512 == 0 &&
                                  (half_raw + ROW512 - 1) / ROW512 <= 10 && D % spl == 0;
             const int nt = half_ok ? 512 : (W >= 1024 ? 1024 : 512);
-            const uint32_t fl = kGeoPackedTile | kGeoDeferFft | (half_ok ? (kGeoHalfTile | kGeoFastP1 | kGeoNtLoads) : (rows_aligned(nt, 1) ? (kGeoFastP1 | kGeoNtLoads) : 0u));
+            const uint32_t fl = kGeoPackedTile | kGeoDeferFft | (half_ok ? (kGeoHalfTile | kGeoFastP1 | kGeoNtLoads) : (rows_aligned(nt, 1) ? (kGeoFastP1 | kGeoNtLoads | kGeoNtInner) : 0u));
             if (lds_for(1, W, S, D, T_lds, nullptr, 2, 2, lut8, fl) <= kLdsMax) {
                 autosel.valid = true; autosel.G = 1; autosel.nt = nt; autosel.batch = 2; autosel.flags = fl; autosel.firr = 2; autosel.firb = 4;
             }
@@ -1022,7 +1025,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             // FIR leaves a wave idle, the previous tile's FFT + epilogue runs there
             const uint32_t g = W >= 128 ? 1u : 128u / W;
             const bool defer = (g * W) % 64 == 0 && g * W + 64 <= 256;
-            const uint32_t fl = kGeoNoSplit | (defer ? kGeoDeferFft : 0u) | (rows_aligned(256, g) ? (kGeoFastP1 | kGeoNtLoads) : 0u);
+            const uint32_t fl = kGeoNoSplit | (defer ? kGeoDeferFft : 0u) | (rows_aligned(256, g) ? (kGeoFastP1 | kGeoNtLoads | kGeoNtInner) : 0u);
             const uint32_t bt = defer ? 2u : 1u;
             if (p->n_windows >= g && lds_for(g, W, S, D, T_lds, nullptr, 2, bt, lut8, fl) <= kLdsMax / 2) {      // at least two workgroups per CU
                 autosel.valid = true; autosel.G = g; autosel.nt = 256; autosel.batch = bt; autosel.flags = fl;

@@ -248,6 +248,7 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (1, (2_000_000, 16, 40), 128, 128, None, (1, 256, 1, 8, 5, 2, 1 | (516 << 8), 0)),        # cs8 rows of 1024 samples, no shift
     # the built-in cfg2 set (row-aligned phase 1 + nt loads, two windows per tile): 39 windows = a SHORT last tile through the fast path
     (0, (2_000_000, 16, 40), 128, 128, 280_000, (2, 256, 1, 8, 4, 1, 1 | (264 << 8), 0)),
+    (0, (2_000_000, 16, 40), 128, 128, 280_000, (2, 256, 1, 8, 4, 1, 1 | (65800 << 8), 0)),   # + shared rows at the default policy (bit 16)
     # half-window tiles (bit 13): two passes per window into one FFT slot, two workgroups per CU — cfg4's shape, and a 256-point
     # window through the packed lane-per-output FIR with a shift stage
     (0, (5_000_000, 8, 512), 1024, 1024, None, (1, 512, 2, 4, 4, 2, 2 | (8392 << 8), 0)),
@@ -318,7 +319,7 @@ def test_unhinted_plans_select_the_fast_variants(engine, oracle):
     assert len(flagged) >= checked // 3, stats       # the rest: tiles beyond half the LDS, windows of 512+ outputs with short filters, 1024-point windows at D = 32
     # a shape next to the north_star one (192 taps) and a long-window one: the expected flag sets
     p = Q.Plan(0, 21_000_000, 1 << 22, shift_hz=280000, lowpass=(200_000, 32, 192), width=128, kernel_policy=Q.KERNEL_SPECIALISE)
-    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (4 | 8 | 64 | 256) and p.info.threads == 256, (p.info.kernel_kind, p.info.kernel_flags)
+    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (4 | 8 | 64 | 256 | 65536) and p.info.threads == 256, (p.info.kernel_kind, p.info.kernel_flags)
     p = Q.Plan(0, 100_000_000, 1 << 24, lowpass=(5_000_000, 8, 384), width=1024, kernel_policy=Q.KERNEL_SPECIALISE)
     assert p.info.kernel_kind == 2 and p.info.kernel_flags == (128 | 64 | 8 | 256 | 8192) and p.info.threads == 512, (p.info.kernel_kind, p.info.kernel_flags)      # half-window tiles
     # the policy is not consulted for chains the generic policy must keep: overlapping windows, tiny filters
@@ -326,9 +327,9 @@ def test_unhinted_plans_select_the_fast_variants(engine, oracle):
     assert p.info.kernel_flags == 0
 
 
-@pytest.mark.parametrize("lp,W,shift,want_flags", [((200_000, 32, 200), 128, 280_000, 4 | 8 | 64 | 256 | 16384),           # the north_star shape
+@pytest.mark.parametrize("lp,W,shift,want_flags", [((200_000, 32, 200), 128, 280_000, 4 | 8 | 64 | 256 | 65536 | 16384),           # the north_star shape
                                                   ((5_000_000, 8, 512), 1024, None, 128 | 64 | 8 | 256 | 8192 | 16384),  # cfg4's shape
-                                                  ((2_000_000, 16, 40), 128, 280_000, 8 | 256)])                        # a 40-tap filter: nothing to fuse in, the exact built-in kernel
+                                                  ((2_000_000, 16, 40), 128, 280_000, 8 | 256 | 65536)])                        # a 40-tap filter: nothing to fuse in, the exact built-in kernel
 def test_fast_mode_is_opt_in_and_bounded(engine, oracle, lp, W, shift, want_flags):
     """QD_MODE_FAST (SURVEY 8(b) `mode{EXACT_ORDER / FAST}`): a permission to fuse the FIR's multiply-adds.  Never the default; the
     plan says whether its kernel fuses (kernel_flags bit 14); a fused run stays within a few ulp of the window maximum of the exact
