@@ -1305,7 +1305,7 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
         for (uint32_t o = lane; o < n_out_s; o += 64) {
             const float2 xv = fbp[o ^ (geo.W >> 1)];
             const float nm = norm_ref(xv);
-            if (P.epi == 0) outf[o] = nm;
+            if (P.epi == 0) outf[o] = nm;       // (non-temporal stores here measured nothing: 3.343 vs 3.347 ms, round 3)
             else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
         }
     }
