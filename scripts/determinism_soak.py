@@ -10,7 +10,9 @@ import quadrs_amd as Q
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = torch.device("cuda", 0)
-for name, log2, epi in (("cfg3p", 27, 0), ("cfg3p", 27, 2), ("cfg4", 28, 0), ("cfg4", 28, 1), ("cfg3", 27, 0), ("cfg2", 26, 0)):
+HINTS = {"pipe": [1, 256, 1, 8, 6, 2, 2 | (1796 << 8), 0], "pipe3": [12, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0]}      # the role-split experiments
+for name, log2, epi, hint in (("cfg3p", 27, 0, None), ("cfg3p", 27, 2, None), ("cfg4", 28, 0, None), ("cfg4", 28, 1, None), ("cfg3", 27, 0, None), ("cfg2", 26, 0, None),
+                              ("cfg3p", 27, 0, "pipe"), ("cfg3", 27, 0, "pipe3"), ("cfg3", 27, 2, "pipe3")):
     cfg = dict(bench.WORKLOADS[name]); cfg["n"] = 1 << log2
     if name == "cfg4":
         src = torch.empty(cfg["n"], 2, dtype=torch.float32, device=dev)
@@ -18,6 +20,8 @@ for name, log2, epi in (("cfg3p", 27, 0), ("cfg3p", 27, 2), ("cfg4", 28, 0), ("c
     else:
         src = bench.synth_slab(torch, cfg["fmt"], 0, cfg["n"], 0x5EED0002, dev)
     kw = dict(rng=(0.001, 0.5)) if epi == 1 else {}
+    if hint:
+        kw["tile_hint"] = HINTS[hint]
     p = Q.Plan(cfg["fmt"], cfg["sr"], cfg["n"], shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"], epilogue=epi, **kw)
     shape = (p.n_windows,) if epi == 2 else (p.n_windows, cfg["W"])
     dt = torch.float32 if epi == 0 else torch.uint8
@@ -31,5 +35,5 @@ for name, log2, epi in (("cfg3p", 27, 0), ("cfg3p", 27, 2), ("cfg4", 28, 0), ("c
         p.run_device(src, out)
         if not torch.equal(out.view(torch.uint8), ref.view(torch.uint8)):
             bad += 1
-    print(f"{name} epilogue {epi}: kind {p.info.kernel_kind}, {p.n_windows} windows, {runs} runs, differing runs: {bad}", flush=True)
+    print(f"{name} epilogue {epi}{' (' + hint + ')' if hint else ''}: kind {p.info.kernel_kind}, flags {p.info.kernel_flags}, {p.n_windows} windows, {runs} runs, differing runs: {bad}", flush=True)
     del src, ref, out
