@@ -22,12 +22,7 @@ namespace qd {
 
 static const FixedEntry kLongFir[] = {
     // README.md:90-94 / configs[2]  "lowpass -power 200 -decimate 32 200000 | sparkfft -width 64 -stride 16"
-    // cf32 input (the README's own FSK example file): 2048-sample rows, 9 per tile, prefetched 4 rows at a time (a whole
-    // tile in registers spills at 128 VGPRs)
-    // FLAGS 32 (kGeoUnrolledFir): the 400-tap loop as straight-line code in pinned 4-tap blocks (three blocks of LDS reads in
-    // flight) instead of the rolled ping-pong loop: 29.2 -> 27.8 ms on cfg3, and the form a plan-time build can bake the taps into
-    QD_FIXED_NTF(0, 1, 64, 16, 32, 400, 27, 4, false, 4, 1024, 8, 1, 2, 32, "fsk5"),
-    QD_FIXED_NTF(0, 2, 64, 16, 32, 400, 27, 4, false, 4, 1024, 8, 1, 2, 32, "fsk5"),
+    // cf32 input (the README's own FSK example file, BASELINE configs[4]): the three-stage kernel in quadrs_hip.hip (k_chain_pipe3)
 #ifndef QD_DEV_FAST
     // cs8 input (HackRF): 4096-sample rows, 5 per tile, whole-tile register prefetch
     QD_FIXED_NTF(1, 1, 64, 16, 32, 400, 27, 5, true, 4, 1024, 8, 1, 2, 32, "cfg3"),

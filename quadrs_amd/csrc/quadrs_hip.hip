@@ -323,7 +323,16 @@ const FixedEntry kFixed[] = {
     // + bit 16: first and last row of the tile (shared with the neighbouring tiles) at the default policy: another 1.0 %
     QD_FIXED_FB(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 65868, "cfg3p"),
     QD_FIXED_FB(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 65868, "cfg3p"),
-    // README.md:90-94 / configs[2] (64-pt windows, stride 16, 400 taps): qd_longfir.hip
+    // README.md:90-94 / configs[2] / configs[4] (64-pt windows, stride 16, 400 taps), cf32 input: the THREE-STAGE kernel (k_chain_pipe3,
+    // FLAGS 32 | 32768): eight producer waves, four shared-FIR waves and four FFT waves work on consecutive 12-window tiles, one barrier
+    // per tile.  cfg5 (16 GiB cf32 per GPU): 7.50 -> 6.71 ms against the one-tile-per-CU kernel of qd_longfir.hip, identical bytes
+    // (profiles/r03/sweep_cfg5_pipe3.log).  The cs8 form of the same chain (cfg3) stays on the serial kernel: there the overlap only
+    // moves the board to its power cap (25.2 vs 25.6 ms).  nt = 512: rows of 512 producer threads; the launch adds 512 consumer threads.
+    { 0, 1, 64, 16, 32, 400, 12, 4, 512, 2, 1, 32800, 8, true, 8, 1,
+      qd::k_chain_pipe3<0, 1, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 32800>, 8, 4>, "fsk5" },
+    { 0, 2, 64, 16, 32, 400, 12, 4, 512, 2, 1, 32800, 8, true, 8, 1,
+      qd::k_chain_pipe3<0, 2, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 32800>, 8, 4>, "fsk5" },
+    // cs8 input of the same chain (cfg3): qd_longfir.hip
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
     // FLAGS 128 (kGeoPackedTile): the two-outputs-per-lane FIR as straight-line packed code, truncated outputs as in-chain
@@ -1109,7 +1118,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         // baked in (taps as immediates: no LDS reads, no registers for them; cfg3 27.8 -> 24.6 ms): worth a compile only for
         // streams of several GiB, falls back silently.  The packed lane-per-output FIR does not need it: it multiplies by the
         // taps straight out of the register pairs an LDS read delivers (fir_pair), which measures the same as immediates.
-        if (!want && !heavy && !tuned && p->fixed && jit_ok && (p->fixed->flags & kGeoUnrolledFir) &&
+        if (!want && !heavy && !tuned && p->fixed && jit_ok && (p->fixed->flags & kGeoUnrolledFir) && !(p->fixed->flags & kGeoPipe3) &&
             (policy == QD_KERNEL_SPECIALISE || in_bytes >= (4ull << 30))) {
             JitKey k = make_key(G, p->nt, p->fixed->lb, 0, pad, batch, kflags | kGeoBakedTaps);
             // the table's prefetch shape and FIR knobs, not the heuristic ones (e.g. the 4-row chunks of the cf32 FSK kernel)
