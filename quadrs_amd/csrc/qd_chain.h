@@ -2595,11 +2595,15 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3(const ChainPa
             uint32_t voff = tid * VECB;
             if (i + 1 == RCH && kRem != ROW) voff = voff < kLastVec ? voff : kLastVec;
             constexpr int aux = ct_load_aux(GeoT::kFlags);
+            // bit 16: the tile's first and last row are the neighbouring tile's too and keep the default policy (see k_chain)
+            const bool shared_row = (GeoT::kFlags & kGeoNtInner) && (i == 0 || i + 1 == RCH);
             if constexpr (sizeof(Vec) == 16) {
-                const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), aux);
+                const v4u_t w = shared_row ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), 0)
+                                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(i * ROWB), aux);
                 pf[i].x = w.x; pf[i].y = w.y; pf[i].z = w.z; pf[i].w = w.w;
             } else {
-                const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), aux);
+                const v2u_t w = shared_row ? __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), 0)
+                                           : __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(i * ROWB), aux);
                 pf[i].x = w.x; pf[i].y = w.y;
             }
         };

@@ -1008,6 +1008,30 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     const bool fast_mode = d.mode == QD_MODE_FAST && p->has_fir && jit_ok && !tuned;
     const FixedEntry *fixed_exact = p->fixed;
     if (fast_mode) p->fixed = nullptr;
+    if (jit_ok && !tuned && !p->fixed && p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && p->S < p->W && (uint64_t)p->T >= 8ull * p->D) {
+        // Overlapping windows with a long filter (the long-filter class below): the THREE-STAGE kernel (k_chain_pipe3) where its geometry
+        // holds — straight-line shared FIR on 16-byte rows, at most 256 outputs per tile, tiles on row boundaries of 512 producer
+        // threads, two tile buffers in LDS — with the largest such tile.  cfg5's shape: 7.50 -> 6.71 ms against the one-tile-per-CU form.
+        const uint32_t W = p->W, S = p->S, D = p->D, T = p->T, c_half = T - T / 2;
+        const int spl = spl_of(d.format);
+        const uint32_t ntrunc = c_half ? (c_half + D - 1) / D - 1 : 0;
+        const bool geo_ok = ntrunc <= S && D % 2 == 0 && c_half % 2 == 0 && T % 4 == 0 && (c_half % D) % 2 == 0 && D % 4 == 0 && T >= 32 && D % spl == 0 &&
+                            is_pow2(W) && W <= 1024;
+        if (geo_ok) {
+            const uint64_t ROW = 512ull * spl, step = (uint64_t)S * D;
+            uint64_t a = ROW, b = step; while (b) { const uint64_t t = a % b; a = b; b = t; }      // gcd
+            const uint32_t g_unit = (uint32_t)(ROW / a);                                              // tiles start on rows when G is a multiple of this
+            uint32_t best = 0;
+            for (uint32_t g = g_unit; g >= 1 && g <= 64 && (uint64_t)(g - 1) * S + W <= 256; g += g_unit) {
+                const uint64_t tile_raw = (uint64_t)(g - 1) * S * D + (uint64_t)W * D + T;
+                if ((tile_raw + ROW - 1) / ROW > 10) break;
+                if (lds_for(g, W, S, D, T_lds, nullptr, 2, 1, lut8, kGeoUnrolledFir | kGeoPipe3) > kLdsMax) break;
+                if (p->n_windows < g) break;
+                best = g;
+            }
+            if (best) { autosel.valid = true; autosel.G = best; autosel.nt = 512; autosel.batch = 1; autosel.flags = kGeoUnrolledFir | kGeoPipe3; }
+        }
+    }
     if (jit_ok && !tuned && !p->fixed && p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && p->S >= p->W) {
         const uint32_t W = p->W, S = p->S, D = p->D, T = p->T, c_half = T - T / 2;
         const int spl = spl_of(d.format);

@@ -322,7 +322,10 @@ def test_unhinted_plans_select_the_fast_variants(engine, oracle):
     assert p.info.kernel_kind == 2 and p.info.kernel_flags == (4 | 8 | 64 | 256 | 65536) and p.info.threads == 256, (p.info.kernel_kind, p.info.kernel_flags)
     p = Q.Plan(0, 100_000_000, 1 << 24, lowpass=(5_000_000, 8, 384), width=1024, kernel_policy=Q.KERNEL_SPECIALISE)
     assert p.info.kernel_kind == 2 and p.info.kernel_flags == (128 | 64 | 8 | 256 | 8192) and p.info.threads == 512, (p.info.kernel_kind, p.info.kernel_flags)      # half-window tiles
-    # the policy is not consulted for chains the generic policy must keep: overlapping windows, tiny filters
+    # overlapping windows with a long filter: the three-stage kernel with the largest tile that fits (12 windows of stride 16 at D = 16)
+    p = Q.Plan(0, 21_000_000, 1 << 24, shift_hz=280000, lowpass=(200_000, 16, 400), width=64, stride=16, kernel_policy=Q.KERNEL_SPECIALISE)
+    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (32 | 32768) and p.info.threads == 1024 and p.info.tile_windows == 12, (p.info.kernel_flags, p.info.tile_windows)
+    # the policy is not consulted for chains the generic policy must keep: short filters
     p = Q.Plan(0, 21_000_000, 1 << 22, lowpass=(2_000_000, 16, 24), width=128, kernel_policy=Q.KERNEL_SPECIALISE)
     assert p.info.kernel_flags == 0
 

@@ -71,6 +71,11 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=Fa
                 D = int(rng.choice([4, 8, 16, 32]))
                 T = int(rng.choice([64, 72, 96, 128, 160, 192, 200, 256, 384, 400, 512]))
                 fmt = int(rng.choice([0, 0, 1, 3]))
+                if rng.random() < 0.3:                 # overlapping windows with a long filter: the three-stage kernel's family
+                    W = int(rng.choice([64, 128]))
+                    S = int(rng.choice([16, W // 4, W // 2]))
+                    D = int(rng.choice([8, 16, 32]))
+                    T = int(rng.choice([t for t in (128, 200, 256, 400, 512) if t >= 8 * D]))
             if variants_only:                       # geometries the FLAGS_ variants apply to, every shape with a variant tiling
                 D = int(rng.choice([8, 16, 32, 64]))
                 T = int(rng.choice([32, 40, 48, 64, 96, 128, 200, 256, 400, 512, 800]))
