@@ -604,7 +604,6 @@ constexpr size_t kLdsMax = 160 * 1024;
 struct RowTab {
     RowBase *d = nullptr;
     uint64_t cap = 0, row0 = 0, rows = 0;
-    hipStream_t last = nullptr;
     bool used = false;
 };
 // tables one launch context needs: the main kernel's rows and, for plans whose main kernel is not 256 threads wide,
@@ -678,10 +677,10 @@ uint64_t out_bytes_per_window(const qd_plan *p) {
 
 int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowTab *t, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
     const uint64_t r_lo = n_lo / ROW, r_hi = (n_hi + ROW - 1) / ROW + 1;
-    if (t->d && r_lo >= t->row0 && r_hi <= t->row0 + t->rows) { t->last = st; t->used = true; return QD_OK; }
-    // The table is about to be rewritten: whatever read it last must have finished.  Work on `st` itself is ordered
-    // behind k_rowtab by the stream; a different stream is drained first.
-    if (t->used && t->last != st) HIPCHK(hipStreamSynchronize(t->last));
+    if (t->d && r_lo >= t->row0 && r_hi <= t->row0 + t->rows) { t->used = true; return QD_OK; }
+    // The table is about to be rewritten: whatever read it last must have finished.  launch_chain has already ordered `st` behind
+    // the context's previous launch (NcoTabs::done — an event, not the earlier caller's stream handle, which may be destroyed by
+    // now), so k_rowtab on `st` runs after every earlier reader.
     const uint64_t rows = r_hi - r_lo;
     if (rows > t->cap) {
         if (t->d) { if (t->used) HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(t->d)); t->d = nullptr; t->cap = 0; }
@@ -689,7 +688,7 @@ int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowTab *t, uint64_t n_lo, uint64
         HIPCHK(hipMalloc(&t->d, cap * sizeof(RowBase)));
         t->cap = cap;
     }
-    t->row0 = r_lo; t->rows = rows; t->last = st; t->used = true;
+    t->row0 = r_lo; t->rows = rows; t->used = true;
     const uint32_t blocks = (uint32_t)((rows + 255) / 256);
     hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, t->d);
     HIPCHK(hipGetLastError());
@@ -1164,10 +1163,10 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // hardware maximum (160 KiB), never to one plan's tile — a later plan with a smaller tile must not lower the limit
     // under a live plan with a larger one (tests/test_gpu_robustness.py::test_two_live_plans_with_different_lds).
     if (p->jit_fn) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) != hipSuccess)
-            p->jit_fn = nullptr;     // fall back to the generic kernel
+        // the tiling (G, threads, LDS layout) was chosen for THIS kernel: the generic kernels cannot run in it, so no silent fallback
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p->jit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax); e != hipSuccess)
+            return fail(QD_ERR_HIP, "hipFuncSetAttribute(plan-time kernel, max dynamic LDS %zu): %s", kLdsMax, hipGetErrorString(e));
     }
-    if (heavy && !p->jit_fn) { p->nt = kThreads; p->launch_nt = kThreads; }
     for (chain_fn f : {p->fn, p->fn_unaligned}) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
         if (e != hipSuccess)
@@ -1625,12 +1624,13 @@ struct Workspace {
     void *buf[kSlots] = {};
     size_t cap[kSlots] = {};
     int device = 0;
-    hipStream_t last = nullptr;
+    hipStream_t last = nullptr;          // compared, never dereferenced: the caller may have destroyed it since
+    hipEvent_t done = nullptr;           // recorded behind the last call that used the buffers
     bool used = false;
     int get(int i, size_t bytes, void **out) {
         if (bytes > cap[i]) {
             if (buf[i]) {
-                if (used) HIPCHK(hipStreamSynchronize(last));
+                if (used && done) HIPCHK(hipEventSynchronize(done));      // earlier calls; this call has not touched slot i yet
                 HIPCHK(hipFree(buf[i]));
                 buf[i] = nullptr; cap[i] = 0;
             }
@@ -1643,6 +1643,8 @@ struct Workspace {
     }
     void release_buffers() {
         for (int i = 0; i < kSlots; ++i) { if (buf[i]) (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+        if (done) (void)hipEventDestroy(done);
+        done = nullptr;
     }
 };
 
@@ -1651,8 +1653,9 @@ std::vector<Workspace *> g_ws_idle;
 
 struct WsLease {                        // one workspace for the duration of a call
     Workspace *ws = nullptr;
+    hipStream_t st_ = nullptr;
     int rc = QD_OK;
-    explicit WsLease(hipStream_t st) {
+    explicit WsLease(hipStream_t st) : st_(st) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         {
@@ -1666,10 +1669,16 @@ struct WsLease {                        // one workspace for the duration of a c
             if (pick < g_ws_idle.size()) { ws = g_ws_idle[pick]; g_ws_idle.erase(g_ws_idle.begin() + pick); }
         }
         if (!ws) { ws = new Workspace(); ws->device = dev; }
-        if (ws->used && ws->last != st && hipStreamSynchronize(ws->last) != hipSuccess) rc = fail(QD_ERR_HIP, "workspace hand-over: stream synchronise failed");
+        // hand-over between streams: the new stream waits (on the device) for the event behind the workspace's last call
+        if (ws->used && ws->last != st && ws->done && hipStreamWaitEvent(st, ws->done, 0) != hipSuccess) rc = fail(QD_ERR_HIP, "workspace hand-over: hipStreamWaitEvent failed");
+        if (!ws->done && hipEventCreateWithFlags(&ws->done, hipEventDisableTiming) != hipSuccess) { ws->done = nullptr; rc = fail(QD_ERR_HIP, "workspace: hipEventCreate failed"); }
         ws->last = st; ws->used = true;
     }
-    ~WsLease() { std::lock_guard<std::mutex> lock(g_ws_mu); g_ws_idle.push_back(ws); }
+    ~WsLease() {
+        if (ws->done) (void)hipEventRecord(ws->done, st_);         // whatever this call enqueued (also on an error return)
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        g_ws_idle.push_back(ws);
+    }
     int get(int i, size_t bytes, void **out) { return ws->get(i, bytes, out); }
 };
 
@@ -1818,7 +1827,7 @@ int qd_release_workspaces(void) {
         std::lock_guard<std::mutex> lock(g_ws_mu);
         for (Workspace *w : g_ws_idle) {
             DeviceGuard guard(w->device);
-            if (w->used) (void)hipStreamSynchronize(w->last);
+            if (w->used && w->done) (void)hipEventSynchronize(w->done);
             w->release_buffers();
             delete w;
         }

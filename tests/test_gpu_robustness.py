@@ -114,6 +114,59 @@ def test_concurrent_runs_on_one_plan(engine):
     assert not errors and all(bits_equal(r, want) for r in results)
 
 
+def test_caller_streams_may_be_destroyed_between_calls(engine):
+    """The library remembers the last stream of a launch context / workspace only to COMPARE it; ordering across streams is an event.
+    A caller that destroys its stream after a call and comes back on a new one (a table rewrite, a workspace regrow in between)
+    must get the same bits — and no use of the dead handle."""
+    import torch
+    import bench
+    from quadrs_amd import _ffi
+    dev = torch.device("cuda", 0)
+    hip = C.CDLL("libamdhip64.so")
+    L = _ffi.lib()
+
+    def new_stream():
+        h = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(h)) == 0
+        return h
+
+    cfg = bench.WORKLOADS["cfg2"]
+    n = 1 << 22
+    src = bench.synth_slab(torch, 0, 0, n, 0x5EED0002, dev)
+    p = engine.Plan(0, cfg["sr"], n, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
+    want = torch.empty(p.n_windows, cfg["W"], dtype=torch.float32, device=dev)
+    p.run_device(src, want)
+    torch.cuda.synchronize()
+    half = (p.n_windows // 2) & ~1
+    for rnd in range(3):
+        st = new_stream()
+        got = torch.zeros_like(want)
+        # two sub-ranges: the second one makes the launch context rewrite its row table (other rows) on the new stream
+        p.run_device(src, got[:half], first_window=0, n_windows=half, stream=st.value)
+        assert hip.hipStreamSynchronize(st) == 0
+        assert hip.hipStreamDestroy(st) == 0
+        st2 = new_stream()
+        p.run_device(src, got[half:], first_window=half, n_windows=p.n_windows - half, stream=st2.value)
+        assert hip.hipStreamSynchronize(st2) == 0
+        assert hip.hipStreamDestroy(st2) == 0
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), rnd
+    # fine-grained calls: workspaces change hands between streams that no longer exist; growing sizes force a regrow
+    x = torch.randn(8192 * 64, 2, device=dev)
+    for k, rows in enumerate((512, 2048, 8192)):
+        ref = torch.empty(rows, 64, device=dev)
+        _ffi.check(L.qd_set_stream(None))
+        _ffi.check(L.qd_fft_norm_batch(C.c_void_p(x.data_ptr()), 64, rows, 64, C.c_void_p(ref.data_ptr()), _ffi.MEM_DEVICE))
+        torch.cuda.synchronize()
+        st = new_stream()
+        _ffi.check(L.qd_set_stream(st))
+        host_in = x[: rows * 64].cpu().numpy()
+        host_out = np.zeros((rows, 64), dtype=np.float32)
+        _ffi.check(L.qd_fft_norm_batch(host_in.ctypes.data_as(C.c_void_p), 64, rows, 64, host_out.ctypes.data_as(C.c_void_p), _ffi.MEM_HOST))
+        _ffi.check(L.qd_set_stream(None))
+        assert hip.hipStreamDestroy(st) == 0
+        assert np.array_equal(host_out.view(np.int32), ref.cpu().numpy().view(np.int32)), k
+
+
 def test_two_streams_on_one_plan_device_path(engine):
     """every device-path launch of a plan shares one set of tile-queue counters and row tables.  Two launches of ONE
     plan on DIFFERENT streams, each big enough for the dynamic tile queue (>= 4 tiles per workgroup of the grid), must not
