@@ -363,6 +363,16 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
             del host
         else:
             SH.exchange(slab, shards, rank, bps, dist)                                # halo over RCCL/xGMI, once, in place
+        # the exchange step priced on its own (informational): the same exchange once more — it lands the same bytes — between
+        # barriers; the first call above also built the communicator's point-to-point channels
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_x = time.perf_counter()
+        if not args.rehearse:
+            SH.exchange(slab, shards, rank, bps, dist)
+            torch.cuda.synchronize()
+        dist.barrier()
+        exchange_ms = (time.perf_counter() - t_x) * 1e3
     nw = me.w1 - me.w0
     out = torch.empty(nw, cfg["W"], dtype=torch.float32, device=device)
 
@@ -374,6 +384,8 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
     # four windows — the last ones read the halo — are recomputed by a FRESH plan from a small slab generated from scratch, and
     # compared with the rows of the sharded run.  Every rank's verdict is AND-reduced into "seams_verified".
     seams = None
+    if world == 1:
+        exchange_ms = None
     if world > 1:
         ok = True
         if me.halo:
@@ -483,7 +495,9 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
         if power:
             roof["power"] = power
         res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
-               "outputs_finite": finite, "seams_verified": seams, "kernel_kind": int(info.kernel_kind), "kernel_flags": int(info.kernel_flags), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
+               "outputs_finite": finite, "seams_verified": seams,
+               "halo_exchange": None if world == 1 or args.rehearse else {"bytes_per_rank": me.halo * bps, "ms": exchange_ms, "note": "one neighbour send/recv, once per resident slab, outside the timed steps"},
+               "kernel_kind": int(info.kernel_kind), "kernel_flags": int(info.kernel_flags), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
         if with_cpu:
             nwin_cpu = int(min(nw, max(64, (1 << 30) // (info.raw_step * bps))))     # at most 1 GiB of the stream goes to the host
             first, count = plan.src_range(me.w0 + (nw - nwin_cpu) // 2, nwin_cpu)
@@ -702,6 +716,8 @@ def main():
             "roofline": main_res["roofline"],
         }
         if main_res.get("seams_verified") is not None:
+            if main_res.get("halo_exchange"):
+                line["halo_exchange"] = main_res["halo_exchange"]
             line["seams_verified"] = main_res["seams_verified"]     # multi-rank: halo bytes + first / last windows of every rank re-derived locally
         for k in ("cpu_baseline", "cpu_allcores"):
             if k in main_res:
