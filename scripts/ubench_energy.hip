@@ -17,14 +17,15 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-enum { NOP = 0, PK, F32, F64, CVT, LDS_LANE, LDS_BCAST, LDS_WRITE, FIR1, FIR2, HBM, NMODES };
+enum { NOP = 0, PK, F32, F64, CVT, LDS_LANE, LDS_BCAST, LDS_WRITE, FIR1, FIR2, HBM, LDS_LIN, LDS_LANE_ASM, LDS_LIN_ASM, NMODES };
 static const char *kNames[NMODES] = {
     "s_nop (floor: waves resident, nothing issued to the VALU)", "v_pk_mul_f32 / v_pk_add_f32 (the FIR's block)", "v_mul_f32 / v_add_f32, 4 chains",
     "v_fma_f64, 4 chains", "v_cvt_f32_f64", "ds_read_b128 per lane, 272 B lane stride (FIR sample reads)", "ds_read_b128 broadcast (FIR tap reads)",
     "ds_write_b128 per lane (phase-1 park)", "FIR mix R=1: 8 packed VALU + 2 lane reads + 1 broadcast read", "FIR mix R=2: 16 packed VALU + 2 lane reads + 2 broadcast reads",
-    "global_load_dwordx4 stream (16 B / lane, 1 GiB window)"};
+    "global_load_dwordx4 stream (16 B / lane, 1 GiB window)", "ds_read_b128 per lane, 16 B lane stride (one linear KiB per instruction)",
+    "ds_read_b128 per lane, 272 B stride, result unused (asm; no accumulate)", "ds_read_b128 per lane, 16 B stride, result unused (asm)"};
 // wave-instructions of the measured class per wave and outer iteration (16 inner steps)
-static const double kPerIter[NMODES] = {256, 256, 256, 256, 256, 16, 16, 16, 8 * 11, 16 * 20, 4};
+static const double kPerIter[NMODES] = {256, 256, 256, 256, 256, 16, 16, 16, 8 * 11, 16 * 20, 4, 16, 16, 16};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, const f4 *stream, int iters, float seed) {
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void k(float *out, const f4 *stream, int iters
     __syncthreads();
     const char *lane = smem + (threadIdx.x & 63) * 272;
     const char *uni = smem + 32 * 1024;
+    const char *lin = smem + (threadIdx.x & 63) * 16;
     char *wl = smem + threadIdx.x * 16;
     v2f a0 = {seed, 0.f}, a1 = {0.f, seed};
     v2f x0 = {1.0f + threadIdx.x, 2.f}, x1 = {3.f, 4.f}, x2 = {5.f, 6.f}, x3 = {7.f, 8.f};
@@ -108,6 +110,13 @@ __global__ __launch_bounds__(256) void k(float *out, const f4 *stream, int iters
                              : "=&v"(t0.x), "=&v"(t1.x) : "v"(x0), "v"(h01));
             } else if (MODE == LDS_LANE) {
                 acc += *reinterpret_cast<const f4 *>(lane + off);
+            } else if (MODE == LDS_LIN) {
+                acc += *reinterpret_cast<const f4 *>(lin + off);
+            } else if (MODE == LDS_LANE_ASM || MODE == LDS_LIN_ASM) {
+                f4 tmp;
+                const uint32_t addr = (uint32_t)(uintptr_t)((MODE == LDS_LANE_ASM ? lane : lin) + off);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(tmp) : "v"(addr));
+                if (u == 15) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else if (MODE == LDS_BCAST) {
                 acc += *reinterpret_cast<const f4 *>(uni + off);
             } else if (MODE == LDS_WRITE) {
@@ -206,5 +215,8 @@ int main() {
     run<FIR1>(d, stream, &floor_w);
     run<FIR2>(d, stream, &floor_w);
     run<HBM>(d, stream, &floor_w);
+    run<LDS_LIN>(d, stream, &floor_w);
+    run<LDS_LANE_ASM>(d, stream, &floor_w);
+    run<LDS_LIN_ASM>(d, stream, &floor_w);
     return 0;
 }
