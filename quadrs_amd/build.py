@@ -9,10 +9,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-# (source, extra flags): qd_longfir.hip holds the FIR-dominated shape kernels, built without the SLP
-# vectorizer (scalar f32 accumulate chains instead of v_pk_*; see the file header)
-SRC = [(os.path.join(HERE, "csrc", "quadrs_hip.hip"), []),
-       (os.path.join(HERE, "csrc", "qd_longfir.hip"), ["-fno-slp-vectorize"])]
+# (source, extra flags)
+SRC = [(os.path.join(HERE, "csrc", "quadrs_hip.hip"), [])]
 DEPS = [s for s, _ in SRC] + [os.path.join(HERE, "csrc", f) for f in ("qd_chain.h", "qd_device.h", "qd_registry.h")] + [
     os.path.join(ROOT, "include", "quadrs_hip.h")]
 OBJ_DIR = os.path.join(ROOT, "build", "obj")

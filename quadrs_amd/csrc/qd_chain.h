@@ -415,7 +415,8 @@ __device__ __forceinline__ uint32_t pad_index(const GeoT &geo, uint32_t m) {
 template <int FMT, int NT, int NCO, bool INTERIOR, class GeoT>
 __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &geo, const TileGeo &g, int32_t rel,
                                             uint32_t tid, const typename FmtTraits<FMT>::Vec &v, const RowBase &rb,
-                                            const LaneRot *lr, uint32_t lane_pad, const float *lut, float2 *raw) {
+                                            const LaneRot *lr, uint32_t lane_pad, const float *lut, float2 *raw,
+                                            float2 *dup = nullptr, uint32_t dup_limit = 0) {
     using FT = FmtTraits<FMT>;
     constexpr int SPL = FT::SPL;
     constexpr uint32_t ROW = NT * SPL;
@@ -488,6 +489,11 @@ __device__ __forceinline__ void process_row(const ChainParams &P, const GeoT &ge
 #pragma unroll
         for (int u = 0; u < SPL; ++u)
             if (INTERIOR || (m0 + u >= 0 && m0 + u < (int32_t)g.tile_raw)) dst[u] = x[u];
+        if (dup != nullptr && tid * SPL < dup_limit) {        // streaming kernel: the ring's first samples once more behind its end
+            float2 *d2 = dup + (row_pad + (int32_t)lane_pad);
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) d2[u] = x[u];
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
@@ -2727,6 +2733,220 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3(const ChainPa
         if (atomicAdd(&P.work[16 * 8], 1ull) == (unsigned long long)gridDim.x - 1) {
 #pragma unroll
             for (int x = 0; x <= 8; ++x) P.work[16 * x] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- the STREAMING three-stage kernel (FixedGeo FLAGS_ bits 15 + 17)
+//
+// k_chain_pipe3 treats tiles as independent: every tile re-reads, re-shifts and re-filters the (W - S) D + T samples it shares with
+// its predecessor — for a 12-window tile of the 64-point / stride-16 chains 31 % of phase 1 and 25 % of the shared FIR are work the
+// previous tile has already done.  Here a workgroup owns a CONTIGUOUS run of tiles and carries that state in LDS:
+//   * the shifted samples live in a ring of RR rows (+ a mirror of the ring's first (b0 + T) samples behind its end, so that a
+//     chain's straight-line reads never wrap); a step adds exactly N = G S D new samples (RN rows),
+//   * the decimated outputs live in a ring of 3 G S entries (dec) + their truncated snapshots (trc); a step adds exactly G S new
+//     full outputs — the ones whose last tap became available with the step's rows — on G S lanes,
+//   * the FFT stage gathers its windows out of the output ring.
+// Step s = -1 of a run is the cold start (rows [0, N) of the run, outputs [0, f0)), steps 0 .. n-1 are its tiles; the stages run
+// one step apart, one barrier per step, as in k_chain_pipe3.  Runs are a static, equal split of the launch's tiles (no queue: a
+// claimed tile would have to be its predecessor's neighbour).  Products, their order and every rounding are unchanged: output q
+// is the same fir_pair chain over the same shifted samples, computed once instead of up to twice.
+constexpr uint32_t kGeoStream = 131072;
+
+template <int FMT, class GeoT>
+struct Pipe3S {
+    static constexpr uint32_t SPL = FmtTraits<FMT>::SPL, ROW = (uint32_t)kPipe3Prod * SPL;
+    static constexpr uint32_t W = GeoT::W, S = GeoT::S, D = GeoT::D, T = GeoT::T, G = GeoT::G, Dp = GeoT::Dp;
+    static constexpr uint32_t N = G * S * D, RN = N / ROW, GS = G * S;
+    static constexpr uint32_t c_half = T - T / 2, ntrunc = c_half ? (c_half + D - 1) / D - 1 : 0;
+    static constexpr uint32_t f0 = N >= c_half + T ? (N - c_half - T) / D + 1 : 0;          // full outputs the cold start's rows complete
+    static constexpr uint32_t RR = (2 * N + T + 2 * D + ROW - 1) / ROW;                       // ring rows: two steps + a chain's look-back
+    static constexpr uint32_t RINGD = RR * (ROW / D);                                           // ... in LDS rows of D samples
+    static constexpr uint32_t MIRD = (GeoT::b0 + T + D - 1) / D + 1;                            // mirror, in LDS rows
+    static constexpr uint32_t ROWP = (ROW / D) * Dp;                                            // padded elements per row of ROW samples
+    static constexpr uint32_t RAW_ELEMS = ((RINGD + MIRD) * Dp + 1) & ~1u;
+    static constexpr uint32_t DR = 3 * GS;
+    static constexpr bool ok = GeoT::kShared && GeoT::kUnrolledShared && GS <= 256 && GS >= 1 && N % ROW == 0 && ROW % D == 0 && D % SPL == 0 &&
+                               W <= 64 * 16 && f0 >= 1 && f0 <= GS && f0 > W - S && ntrunc <= S && MIRD * D <= ROW && (G - 1) * S + W <= 2 * GS;
+};
+
+template <int FMT, int NCO, class GeoT, int RN_, int LB>
+__global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainParams P) {
+    using FT = FmtTraits<FMT>;
+    using Vec = typename FT::Vec;
+    using K = Pipe3S<FMT, GeoT>;
+    constexpr int SPL = FT::SPL;
+    constexpr bool HAS_SHIFT = NCO != 0;
+    static_assert(K::ok && (uint32_t)RN_ == K::RN, "streaming three-stage kernel: geometry");
+    constexpr uint32_t PT = kPipe3Prod;
+    constexpr uint32_t W = K::W, S = K::S, D = K::D, T = K::T, G = K::G, Dp = K::Dp, logW = GeoT::logW;
+    constexpr uint32_t ROW = K::ROW, ROWB = ROW * FT::BPS, VECB = SPL * FT::BPS, RN = K::RN, RR = K::RR, GS = K::GS, DR = K::DR;
+    constexpr uint32_t GV = (G + 3) / 4;
+    const GeoT geo(P);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *raw = reinterpret_cast<float2 *>(smem);
+    float2 *dec = raw + K::RAW_ELEMS, *trc = dec + DR;
+    float2 *fbx = trc + DR;
+    float2 *twl = fbx + (size_t)G * W;
+    float *tapl = reinterpret_cast<float *>(twl + W);
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const uint32_t n_tw = W - geo.base_len;
+        for (uint32_t i = tid; i < n_tw; i += kPipe3Threads) twl[i] = P.tw[i];
+        for (uint32_t i = tid; i < T; i += kPipe3Threads) tapl[i] = P.taps[i];
+    }
+    __syncthreads();
+
+    // this workgroup's run: an equal, contiguous share of the launch's tiles
+    const uint64_t n_tiles = (P.n_windows + G - 1) / G;
+    const uint64_t base_cnt = n_tiles / gridDim.x, rem = n_tiles % gridDim.x;
+    const uint64_t t_lo = (uint64_t)blockIdx.x * base_cnt + (blockIdx.x < rem ? blockIdx.x : rem);
+    const uint32_t n_steps = (uint32_t)(base_cnt + (blockIdx.x < rem ? 1u : 0u));
+    if (n_steps == 0) return;                                                      // uniform over the workgroup
+    const uint32_t n_iter = n_steps + 3;
+    auto g_cnt_of = [&](uint64_t t) -> uint32_t {
+        const uint64_t w0 = t * G, left = P.n_windows - w0;
+        return left < G ? (uint32_t)left : G;
+    };
+
+    if (wave < 8) {
+        // ================= producers: step s = it - 1 parks rows [(s + 1) RN, (s + 2) RN) of the run in the ring
+        LaneRot lr[SPL];
+        if constexpr (HAS_SHIFT) {
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                const uint32_t j = tid * SPL + u;
+                const double2 cs = P.jtab[j];
+                lr[u].jf = (double)j; lr[u].c = cs.x; lr[u].s = cs.y;
+            }
+        }
+        const uint32_t lane_pad = pad_index(geo, tid * SPL);
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+        typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+        const uint64_t n0 = (P.first_window + t_lo * G) * ((uint64_t)S * D);        // the run's first raw sample (a row boundary)
+        auto rsrc_of = [&](uint32_t step1) {                                       // step1 = s + 1: rows [step1 RN, (step1 + 1) RN)
+            const uint64_t ns = n0 + (uint64_t)step1 * K::N;
+            const uint64_t end = P.src_first + P.src_count;
+            const uint64_t left = ns < end ? (end - ns) * FT::BPS : 0;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * FT::BPS, 0,
+                                                     left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
+        };
+        Vec pf[RN];
+        auto load_row = [&](const decltype(rsrc_of(0)) &rsrc, int i) {
+            constexpr int aux = ct_load_aux(GeoT::kFlags);                          // every row is read exactly once: all of them may go non-temporal
+            if constexpr (sizeof(Vec) == 16) {
+                const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(tid * VECB), (int)(i * ROWB), aux);
+                pf[i].x = w.x; pf[i].y = w.y; pf[i].z = w.z; pf[i].w = w.w;
+            } else {
+                const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(tid * VECB), (int)(i * ROWB), aux);
+                pf[i].x = w.x; pf[i].y = w.y;
+            }
+        };
+        double rt_touch = 0.0;
+        TileGeo gl{};
+        gl.tile_raw = ROW;
+        __builtin_amdgcn_s_setprio(0);
+        {
+            const auto rsrc = rsrc_of(0);
+#pragma unroll
+            for (int i = 0; i < (int)RN; ++i) load_row(rsrc, i);
+        }
+        uint32_t slot0 = 0;                                                         // ring row of the step's first row
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            if (it <= n_steps && !QD_DBG(P, 256)) {
+                const uint32_t step1 = it;                                          // s + 1
+                const uint32_t pf1 = it < n_steps ? it + 1 : it;                    // last step: harmless re-loads
+                const auto rsrc = rsrc_of(pf1);
+                const uint64_t ns = n0 + (uint64_t)step1 * K::N;
+                const_f64_p rows = (const_f64_p)(uintptr_t)(P.rowtab + (ns / ROW - P.rowtab_row0));
+                if constexpr (HAS_SHIFT) {                                          // L2 touch of the next step's row bases
+                    uint32_t r = tid < RN ? tid : RN - 1;
+                    asm volatile("" : "+v"(r));
+                    rt_touch += P.rowtab[(n0 + (uint64_t)pf1 * K::N) / ROW - P.rowtab_row0 + r].c;
+                }
+                RowBase rb_next{};
+                if constexpr (HAS_SHIFT) rb_next = load_rowbase_at(rows, 0);
+#pragma unroll
+                for (int i = 0; i < (int)RN; ++i) {
+                    const Vec v = pf[i];
+                    const RowBase rb = rb_next;
+                    if constexpr (HAS_SHIFT) { if (i + 1 < (int)RN) rb_next = load_rowbase_at(rows, i + 1); }
+                    uint32_t slot = slot0 + (uint32_t)i;
+                    if (slot >= RR) slot -= RR;
+                    float2 *dst = raw + (size_t)slot * K::ROWP;
+                    float2 *mir = slot == 0 ? raw + (size_t)K::RINGD * Dp : nullptr;    // the ring's first samples once more behind its end
+                    process_row<FMT, PT, NCO, true>(P, geo, gl, 0, tid, v, rb, lr, lane_pad, nullptr, dst, mir, K::MIRD * D);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_row(rsrc, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                slot0 += RN;
+                if (slot0 >= RR) slot0 -= RR;
+            }
+            __syncthreads();
+        }
+        if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
+    } else if (wave < 12) {
+        // ================= the shared FIR: step s = it - 2 computes the G S outputs its rows completed (the cold start: f0)
+        __builtin_amdgcn_s_setprio(2);
+        constexpr uint32_t ntrunc = K::ntrunc;
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            if (it >= 1 && it <= n_steps + 1) {
+                const uint32_t q_lo = it == 1 ? 0u : K::f0 + (it - 2) * GS, cnt = it == 1 ? K::f0 : GS;
+                uint32_t l = tid - (uint32_t)kPipe3Prod;
+                asm volatile("" : "+v"(l));
+                if (l < cnt && !QD_DBG(P, 64)) {
+                    const uint32_t q = q_lo + l;                                    // run-local output index
+                    uint32_t jmax = T;
+                    if (q + ntrunc >= W) {                                          // may be in the truncated tail of a window of the run
+                        const uint32_t g = (q - (W - ntrunc)) / S, k = q - g * S;
+                        if (k < W) { const uint32_t jm = (W - k) * D + T / 2; if (jm < T) jmax = jm; }
+                    }
+                    const uint32_t drow = (q + geo.a0) % K::RINGD;
+                    const float2 *rowp = raw + (size_t)drow * Dp;
+                    float2 snap = make_float2(0.f, 0.f);
+                    const float2 full = fir_pair<GeoT, true>(rowp, jmax, tapl, &snap);
+                    const uint32_t pos = q % DR;
+                    dec[pos] = full;
+                    if (jmax < T) trc[pos] = snap;
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ================= gather + FFT + |X| of step s = it - 3: wave v takes windows [v GV, (v + 1) GV) of the tile, all wave-local
+        __builtin_amdgcn_s_setprio(1);
+        const uint32_t v = wave - 12;
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            if (it >= 3) {
+                const uint32_t s = it - 3;
+                const uint64_t t = t_lo + s;
+                const uint32_t g_cnt = g_cnt_of(t);
+                const uint32_t g0 = v * GV, g1 = (g0 + GV < g_cnt) ? g0 + GV : g_cnt;
+                if (g0 < g1 && !QD_DBG(P, 128)) {
+                    float2 *fbw = fbx + (size_t)g0 * W;
+                    uint32_t lane = tid & 63u;
+                    asm volatile("" : "+v"(lane));
+                    constexpr uint32_t log_width = 2 * GeoT::layers;
+                    const uint32_t n_o = (g1 - g0) << logW;
+                    const uint32_t q_base = s * GS;
+                    for (uint32_t o = lane; o < n_o; o += 64) {
+                        const uint32_t gl_ = o >> logW, k = o & (W - 1);
+                        const uint32_t pos = (q_base + (g0 + gl_) * S + k) % DR;
+                        const bool tr = (W - k) * D + T / 2 < T;
+                        const float2 val = tr ? trc[pos] : dec[pos];
+                        const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                        fbw[(gl_ << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = val;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    wave_fft_epilogue_fn<GeoT>(P, geo, twl, fbw, P.first_window + t * G + g0, g1 - g0, tid);
+                }
+            }
+            __syncthreads();
         }
     }
 }

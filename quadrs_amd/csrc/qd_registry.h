@@ -1,6 +1,5 @@
 // qd_registry.h — table entries of the shape-specialised (FixedGeo) chain kernels.
-// Two translation units contribute entries: quadrs_hip.hip (default flags) and qd_longfir.hip
-// (FIR-dominated shapes, compiled with -fno-slp-vectorize, see there).
+// (the table itself is kFixed in quadrs_hip.hip)
 #pragma once
 #include "qd_chain.h"
 
@@ -29,8 +28,5 @@ struct FixedEntry {
 
 #define QD_FIXED_NTF(F, NCO, W, S, D, T, G, RCH, WHOLE, LB, NT, FIRB, FIRR, PAD, FLAGS, NAME) \
     { F, NCO, W, S, D, T, G, LB, NT, PAD, 1, FLAGS, RCH, WHOLE, FIRB, FIRR, qd::k_chain<F, NCO, qd::FixedGeo<W, S, D, T, G, FIRB, FIRR, PAD, 1, FLAGS>, true, RCH, WHOLE, true, LB, NT>, NAME }
-
-// defined in qd_longfir.hip
-const FixedEntry *longfir_entries(int *count);
 
 }  // namespace qd

@@ -323,16 +323,24 @@ const FixedEntry kFixed[] = {
     // + bit 16: first and last row of the tile (shared with the neighbouring tiles) at the default policy: another 1.0 %
     QD_FIXED_FB(0, 1, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 65868, "cfg3p"),
     QD_FIXED_FB(0, 2, 128, 128, 32, 200, 1, 9, true, 4, 2, 2, 65868, "cfg3p"),
-    // README.md:90-94 / configs[2] / configs[4] (64-pt windows, stride 16, 400 taps), cf32 input: the THREE-STAGE kernel (k_chain_pipe3,
-    // FLAGS 32 | 32768): eight producer waves, four shared-FIR waves and four FFT waves work on consecutive 12-window tiles, one barrier
-    // per tile.  cfg5 (16 GiB cf32 per GPU): 7.50 -> 6.71 ms against the one-tile-per-CU kernel of qd_longfir.hip, identical bytes
-    // (profiles/r03/sweep_cfg5_pipe3.log).  The cs8 form of the same chain (cfg3) stays on the serial kernel: there the overlap only
-    // moves the board to its power cap (25.2 vs 25.6 ms).  nt = 512: rows of 512 producer threads; the launch adds 512 consumer threads.
-    { 0, 1, 64, 16, 32, 400, 12, 4, 512, 2, 1, 32800, 8, true, 8, 1,
-      qd::k_chain_pipe3<0, 1, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 32800>, 8, 4>, "fsk5" },
-    { 0, 2, 64, 16, 32, 400, 12, 4, 512, 2, 1, 32800, 8, true, 8, 1,
-      qd::k_chain_pipe3<0, 2, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 32800>, 8, 4>, "fsk5" },
-    // cs8 input of the same chain (cfg3): qd_longfir.hip
+    // README.md:90-94 / configs[2] / configs[4] (64-pt windows, stride 16, 400 taps): the STREAMING three-stage kernel
+    // (k_chain_pipe3s, FLAGS 32 | 256 | 32768 | 131072): eight producer waves, the shared-FIR waves and four FFT waves work one step
+    // apart on a contiguous run of tiles per workgroup; shifted samples and decimated outputs are carried from tile to tile in LDS
+    // rings, so a step shifts and filters only what is NEW (a 12-window tile of the plain three-stage kernel repeated 31 % of its
+    // phase 1 and 25 % of its FIR).  cf32 (cfg5, 16 GiB per GPU): one-tile-per-CU kernel 7.50 ms -> three-stage 6.71 -> streaming,
+    // 14-window steps 5.7 ms; cs8 (cfg3): 25.6 -> 22 ms (12-window steps: 16 would need 174 KiB of LDS).  Identical bytes
+    // (profiles/r03/sweep_stream.log).  nt = 512: rows of 512 producer threads; the launch adds 512 consumer threads.
+    { 0, 1, 64, 16, 32, 400, 14, 4, 512, 2, 1, 164128, 7, true, 8, 1,
+      qd::k_chain_pipe3s<0, 1, qd::FixedGeo<64, 16, 32, 400, 14, 8, 1, 2, 1, 164128>, 7, 4>, "fsk5" },
+    { 0, 2, 64, 16, 32, 400, 14, 4, 512, 2, 1, 164128, 7, true, 8, 1,
+      qd::k_chain_pipe3s<0, 2, qd::FixedGeo<64, 16, 32, 400, 14, 8, 1, 2, 1, 164128>, 7, 4>, "fsk5" },
+#ifndef QD_DEV_FAST
+    // cs8 input (HackRF) of the same chain: rows of 2048 samples, three per step
+    { 1, 1, 64, 16, 32, 400, 12, 4, 512, 2, 1, 164128, 3, true, 8, 1,
+      qd::k_chain_pipe3s<1, 1, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 164128>, 3, 4>, "cfg3" },
+    { 1, 2, 64, 16, 32, 400, 12, 4, 512, 2, 1, 164128, 3, true, 8, 1,
+      qd::k_chain_pipe3s<1, 2, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 164128>, 3, 4>, "cfg3" },
+#endif
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
     // FLAGS 128 (kGeoPackedTile): the two-outputs-per-lane FIR as straight-line packed code, truncated outputs as in-chain
@@ -350,10 +358,6 @@ const FixedEntry kFixed[] = {
 const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t D, uint32_t T) {
     for (const FixedEntry &e : kFixed)
         if (e.fmt == fmt && e.nco == nco && e.W == W && e.S == S && e.D == D && e.T == T) return &e;
-    int n_long = 0;
-    const FixedEntry *lf = longfir_entries(&n_long);
-    for (int i = 0; i < n_long; ++i)
-        if (lf[i].fmt == fmt && lf[i].nco == nco && lf[i].W == W && lf[i].S == S && lf[i].D == D && lf[i].T == T) return &lf[i];
     return nullptr;
 }
 
@@ -430,6 +434,10 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         return nullptr;
     }
     char name[512];
+    if ((k.flags & kGeoPipe3) && (k.flags & kGeoStream))       // ... its streaming form: contiguous runs of tiles, state carried in LDS rings
+        snprintf(name, sizeof name, "qd::k_chain_pipe3s<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb);
+    else
     if (k.flags & kGeoPipe3)       // the three-stage kernel for overlapping windows (k_chain_pipe3): 512 producer threads + FIR + FFT waves
         snprintf(name, sizeof name, "qd::k_chain_pipe3<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
                  k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb);
@@ -464,7 +472,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
 #ifdef QD_WGTIME
     optv.push_back("-DQD_WGTIME");
 #endif
-    if (k.noslp || dev_env("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");   // scalar f32 accumulate chains (see qd_longfir.hip)
+    if (k.noslp || dev_env("QD_JIT_NOSLP")) optv.push_back("-fno-slp-vectorize");   // scalar f32 accumulate chains of the long-filter policy
     std::vector<std::string> extra;                          // development: QD_JIT_FLAGS="-mllvm -foo ..." appended verbatim
     if (const char *e = dev_env("QD_JIT_FLAGS")) {
         std::string cur;
@@ -552,7 +560,7 @@ struct Geometry {
 // twiddles | taps | 8-bit LUT | shared-FIR dec/trc | batch bookkeeping.  The generic kernels (interleaved tile, pad 1, batch 1,
 // taps in LDS) run inside the same allocation for the unaligned slab tail, so the size is the larger of the two layouts.
 size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems, uint32_t pad_per_row = 1, uint32_t batch = 1,
-               bool lut8 = true, uint32_t flags = 0, size_t *main_only = nullptr) {
+               bool lut8 = true, uint32_t flags = 0, size_t *main_only = nullptr, int stream_spl = 2 /* samples per lane and row load (streaming kernel) */) {
     uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
     const uint64_t full_raw = tile_raw;
     if ((flags & kGeoHalfTile) && G == 1 && T > 0 && S >= W) tile_raw = (T - T / 2) + (W / 2 - 1) * D + T;     // FixedGeo::kHalfRaw
@@ -582,6 +590,16 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     const bool baked = planar && (flags & kGeoBakedTaps);
     const uint64_t main_b = elems * 8 + (uint64_t)batch * G * W * 8 + W * 8 + (baked ? 0 : taps_b) + lut_b + shared_fir + (uint64_t)batch * 16 + 16;
     const uint64_t generic_b = gen_elems_of(full_raw) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16 + 16;
+    if ((flags & kGeoPipe3) && (flags & kGeoStream)) {
+        // k_chain_pipe3s (qd_chain.h, Pipe3S): sample ring + mirror | dec + trc rings of 3 G S | G*W FFT buffers | twiddles | taps
+        const uint64_t row = 512ull * stream_spl, n_new = (uint64_t)G * S * D, dp = D + ((D % 2 == 0) ? pad_per_row : 0);
+        const uint64_t rr = (2 * n_new + T + 2 * D + row - 1) / row, ringd = rr * (row / D);
+        const uint64_t c = T - T / 2, mird = ((c % D) + T + D - 1) / D + 1;
+        const uint64_t raw_e = ((ringd + mird) * dp + 1) & ~1ull;
+        const uint64_t p3 = raw_e * 8 + 2 * 3 * (uint64_t)G * S * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + 64;
+        if (main_only) *main_only = (size_t)p3;
+        return (size_t)(p3 > generic_b ? p3 : generic_b);
+    }
     if (flags & kGeoPipe3) {
         // k_chain_pipe3: two raw tiles | dec + trc of two sets | G*W FFT buffers | twiddles | taps | queue hand-over
         const uint64_t qp = (((uint64_t)(G - 1) * S + W) + 1) & ~1ull;
@@ -722,7 +740,8 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     if (tabs->launched && tabs->last_stream != st) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));      // see NcoTabs
     if (p->has_shift) {
         // row-aligned phase 1: rows of a short last tile's missing windows (and a half-window pass's read-ahead) get table entries too
-        const uint64_t extra = ((p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed)) ? (uint64_t)p->geo.G * p->S * p->D + p->T : 0;
+        // (the streaming kernel parks one more step of rows behind a run's last tile)
+        const uint64_t extra = ((p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed)) ? (uint64_t)p->geo.G * p->S * p->D * ((p->kflags & kGeoStream) ? 2 : 1) + p->T : 0;
         rc = ensure_rowtab_for(p, p->nt * spl_of(fmt), &tabs->main, need0, need1 + extra, st);
         if (rc) return rc;
     }
@@ -962,8 +981,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 131071 &&
-              lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags) <= kLdsMax))
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 262143 &&
+              lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags, nullptr, spl_of(d.format)) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
         tuned = true;
@@ -984,7 +1003,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         if ((flagsv & kGeoHalfTile) && g == 1 && p->S >= p->W) tile_raw = (p->T - p->T / 2) + (uint64_t)(p->W / 2 - 1) * p->D + p->T;      // rows of ONE pass
         // a run may start at any window, so a tile starts on a row boundary only if S*D is a multiple of ROW
         const bool tiles_on_rows = (((uint64_t)p->S * p->D) % ROW) == 0 || ((flagsv & (kGeoFastP1 | kGeoPipe3)) && (((uint64_t)g * p->S * p->D) % ROW) == 0);
-        const uint64_t rows = (tile_raw + ROW - 1) / ROW + (tiles_on_rows ? 0 : 1);
+        uint64_t rows = (tile_raw + ROW - 1) / ROW + (tiles_on_rows ? 0 : 1);
+        if ((flagsv & kGeoPipe3) && (flagsv & kGeoStream)) rows = ((uint64_t)g * p->S * p->D) / ROW;      // rows per step of the streaming kernel
         if ((flagsv & kGeoUnrolledFir) && !(flagsv & kGeoPipe3)) noslp = 1;       // its scalar accumulate chains must stay scalar (the three-stage kernel's FIR is the packed asm form)
         return JitKey{d.format, p->nco, p->has_fir ? 1 : 0, rows <= 10 ? (int)rows : 4, rows <= 10 ? 1 : 0, lb, nt,
                       p->W, p->S, p->D, p->T, g, tune[3], tune[2], noslp, padv, batchv, flagsv,
@@ -1020,15 +1040,30 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             const uint64_t ROW = 512ull * spl, step = (uint64_t)S * D;
             uint64_t a = ROW, b = step; while (b) { const uint64_t t = a % b; a = b; b = t; }      // gcd
             const uint32_t g_unit = (uint32_t)(ROW / a);                                              // tiles start on rows when G is a multiple of this
+            // (1) the STREAMING form (k_chain_pipe3s): a step adds G S new outputs on G S FIR lanes and G S D new samples; the step with
+            // the most outputs that the rings leave room for (the FIR stage is bound by the latency of one wave's pass over the T taps,
+            // so outputs per pass is what counts).  The conditions restate Pipe3S<>::ok (qd_chain.h).
+            uint32_t best_s = 0;
+            for (uint32_t g = g_unit; g >= 1 && g <= 64 && (uint64_t)g * S <= 256; g += g_unit) {
+                const uint64_t n_new = (uint64_t)g * S * D, gs = (uint64_t)g * S;
+                if (n_new < (uint64_t)c_half + T) continue;
+                const uint64_t f0 = (n_new - c_half - T) / D + 1, mird = ((c_half % D) + T + D - 1) / D + 1;
+                if (!(ROW % D == 0 && f0 <= gs && f0 > W - S && mird * D <= ROW && (uint64_t)(g - 1) * S + W <= 2 * gs && n_new / ROW <= 10)) continue;
+                if (lds_for(g, W, S, D, T_lds, nullptr, 2, 1, lut8, kGeoUnrolledFir | kGeoPipe3 | kGeoStream, nullptr, spl) > kLdsMax) break;
+                if (p->n_windows < g) break;
+                best_s = g;
+            }
+            // (2) the tile-at-a-time three-stage kernel, where the streaming form's geometry fails
             uint32_t best = 0;
-            for (uint32_t g = g_unit; g >= 1 && g <= 64 && (uint64_t)(g - 1) * S + W <= 256; g += g_unit) {
+            for (uint32_t g = g_unit; !best_s && g >= 1 && g <= 64 && (uint64_t)(g - 1) * S + W <= 256; g += g_unit) {
                 const uint64_t tile_raw = (uint64_t)(g - 1) * S * D + (uint64_t)W * D + T;
                 if ((tile_raw + ROW - 1) / ROW > 10) break;
                 if (lds_for(g, W, S, D, T_lds, nullptr, 2, 1, lut8, kGeoUnrolledFir | kGeoPipe3) > kLdsMax) break;
                 if (p->n_windows < g) break;
                 best = g;
             }
-            if (best) { autosel.valid = true; autosel.G = best; autosel.nt = 512; autosel.batch = 1; autosel.flags = kGeoUnrolledFir | kGeoPipe3; }
+            if (best_s) { autosel.valid = true; autosel.G = best_s; autosel.nt = 512; autosel.batch = 1; autosel.flags = kGeoUnrolledFir | kGeoPipe3 | kGeoStream | kGeoNtLoads; }
+            else if (best) { autosel.valid = true; autosel.G = best; autosel.nt = 512; autosel.batch = 1; autosel.flags = kGeoUnrolledFir | kGeoPipe3; }
         }
     }
     if (jit_ok && !tuned && !p->fixed && p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && p->S >= p->W) {
@@ -1107,7 +1142,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->geo.G = G;
     p->kflags = kflags;
     p->launch_nt = p->nt + ((kflags & kGeoPipe3) ? 512 : ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0));
-    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main, spl_of(d.format));     // the generic kernels (pad 1, batch 1) fit inside the same allocation
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);

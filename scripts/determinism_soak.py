@@ -10,9 +10,9 @@ import quadrs_amd as Q
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = torch.device("cuda", 0)
-HINTS = {"pipe": [1, 256, 1, 8, 6, 2, 2 | (1796 << 8), 0], "pipe3": [12, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0]}      # the role-split experiments
+HINTS = {"pipe": [1, 256, 1, 8, 6, 2, 2 | (1796 << 8), 0], "pipe3": [12, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0], "pipe3s": [12, 512, 1, 8, 4, 2, 1 | (164128 << 8), 0]}      # the role-split experiments
 for name, log2, epi, hint in (("cfg3p", 27, 0, None), ("cfg3p", 27, 2, None), ("cfg4", 28, 0, None), ("cfg4", 28, 1, None), ("cfg3", 27, 0, None), ("cfg2", 26, 0, None),
-                              ("cfg3p", 27, 0, "pipe"), ("cfg3", 27, 0, "pipe3"), ("cfg3", 27, 2, "pipe3")):
+                              ("cfg3p", 27, 0, "pipe"), ("cfg3", 27, 0, "pipe3"), ("cfg3", 27, 2, "pipe3"), ("cfg5", 27, 0, None), ("cfg5", 27, 1, None), ("cfg5", 27, 2, "pipe3s")):
     cfg = dict(bench.WORKLOADS[name]); cfg["n"] = 1 << log2
     if name == "cfg4":
         src = torch.empty(cfg["n"], 2, dtype=torch.float32, device=dev)

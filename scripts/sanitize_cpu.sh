@@ -33,14 +33,14 @@ echo "== 3. host side of the C ABI under ASan + UBSan (device code uninstrumente
 CLANG_ASAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 mkdir -p "$out/obj"
 ok=1
-for f in quadrs_hip qd_longfir; do
-  extra=""; [ $f = qd_longfir ] && extra="-fno-slp-vectorize"
+for f in quadrs_hip; do
+  extra=""
   /opt/rocm/bin/hipcc -O1 -g -fno-omit-frame-pointer --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -fno-fast-math -I include \
       -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -mllvm -amdgpu-atomic-optimizer-strategy=None $extra \
       -c -o "$out/obj/$f.o" quadrs_amd/csrc/$f.hip > "$out/abi_build_$f.log" 2>&1 || ok=0
 done
 if [ $ok = 1 ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -o "$out/libquadrs_hip_san.so" "$out/obj/quadrs_hip.o" "$out/obj/qd_longfir.o" -lhiprtc -ldl > "$out/abi_link.log" 2>&1 || ok=0
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -o "$out/libquadrs_hip_san.so" "$out/obj/quadrs_hip.o" -lhiprtc -ldl > "$out/abi_link.log" 2>&1 || ok=0
 fi
 if [ $ok = 1 ]; then
   mkdir -p "$out/csrc_link"; ln -sfn "$PWD/quadrs_amd/csrc" "$out/csrc"

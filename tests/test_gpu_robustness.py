@@ -316,6 +316,11 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (1, (200_000, 32, 400), 64, 16, 280_000, (12, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0)),     # cfg3's chain: cs8, 12 windows per tile
     (0, (200_000, 32, 400), 64, 16, 280_000, (12, 512, 1, 8, 4, 2, 1 | (33056 << 8), 0)),     # the README FSK chain: cf32, nt loads
     (3, (300_000, 16, 128), 64, 32, None, (4, 512, 1, 8, 4, 2, 1 | (32800 << 8), 0)),         # cs16, other taps / stride, no shift (4 windows = one row of 2048)
+    # its STREAMING form (k_chain_pipe3s, bits 15 + 17): contiguous runs of tiles per workgroup, samples and outputs carried in LDS rings
+    (1, (200_000, 32, 400), 64, 16, 280_000, (12, 512, 1, 8, 4, 2, 1 | (164128 << 8), 0)),    # the built-in cs8 set (39 windows: runs of one tile, a short last one)
+    (0, (200_000, 32, 400), 64, 16, 280_000, (14, 512, 1, 8, 4, 2, 1 | (164128 << 8), 0)),    # the built-in cf32 set
+    (0, (200_000, 32, 400), 64, 16, 280_000, (6, 512, 1, 8, 4, 2, 1 | (163872 << 8), 0)),     # six-window steps (the smallest the geometry admits here): 96 FIR lanes
+    (3, (300_000, 16, 128), 64, 32, None, (4, 512, 1, 8, 4, 2, 1 | (163872 << 8), 0)),        # cs16, no shift
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift, hint, epi):
@@ -378,9 +383,9 @@ def test_unhinted_plans_select_the_fast_variants(engine, oracle):
     assert p.info.kernel_kind == 2 and p.info.kernel_flags == (4 | 8 | 64 | 256 | 65536) and p.info.threads == 256, (p.info.kernel_kind, p.info.kernel_flags)
     p = Q.Plan(0, 100_000_000, 1 << 24, lowpass=(5_000_000, 8, 384), width=1024, kernel_policy=Q.KERNEL_SPECIALISE)
     assert p.info.kernel_kind == 2 and p.info.kernel_flags == (128 | 64 | 8 | 256 | 8192) and p.info.threads == 512, (p.info.kernel_kind, p.info.kernel_flags)      # half-window tiles
-    # overlapping windows with a long filter: the three-stage kernel with the largest tile that fits (12 windows of stride 16 at D = 16)
+    # overlapping windows with a long filter: the streaming three-stage kernel with the largest step that fits (16 windows of stride 16 = 256 FIR lanes)
     p = Q.Plan(0, 21_000_000, 1 << 24, shift_hz=280000, lowpass=(200_000, 16, 400), width=64, stride=16, kernel_policy=Q.KERNEL_SPECIALISE)
-    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (32 | 32768) and p.info.threads == 1024 and p.info.tile_windows == 12, (p.info.kernel_flags, p.info.tile_windows)
+    assert p.info.kernel_kind == 2 and p.info.kernel_flags == (32 | 256 | 32768 | 131072) and p.info.threads == 1024 and p.info.tile_windows == 16, (p.info.kernel_flags, p.info.tile_windows)
     # the policy is not consulted for chains the generic policy must keep: short filters
     p = Q.Plan(0, 21_000_000, 1 << 22, lowpass=(2_000_000, 16, 24), width=128, kernel_policy=Q.KERNEL_SPECIALISE)
     assert p.info.kernel_flags == 0
@@ -658,6 +663,39 @@ def test_take_fft_any_width_against_f64_dft(engine, oracle, fsk, W, out_len):
             worst_ulp = max(worst_ulp, float((err / np.spacing(ref[r]).astype(np.float64)).max()))
             exact += int((got[r].view(np.uint32) == ref[r].view(np.uint32)).sum())
         record_observed(f"take_fft W={W} windowing={windowing}", rows=out_len, worst_ulp=worst_ulp, exact_fraction=exact / (out_len * W))
+
+
+def test_streaming_three_stage_kernel_long_runs(engine):
+    """k_chain_pipe3s at a size where every workgroup owns a run of ~43 steps (10 923 tiles on 256 workgroups: uneven runs, a short last
+    tile), device path, with a window sub-range that starts on a row boundary inside the stream: bit for bit against the generic
+    kernel, twice (the rings wrap ~7 times per run).  cs8 built-in and a cf32 plan-time build."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    for fmt, hint in ((1, None), (0, [14, 512, 1, 8, 4, 2, 1 | (164128 << 8), 0])):
+        n = (1 << 26) - (0 if fmt == 1 else 40_000)           # window counts that are no multiple of the step (12 / 14)
+        src = bench.synth_slab(torch, fmt, 0, n, 0x5EED0002, dev)
+        kw = dict(shift_hz=280000, lowpass=(200_000, 32, 400), width=64, stride=16)
+        ref = engine.Plan(fmt, 21_000_000, n, kernel_policy=engine.KERNEL_GENERIC, **kw)
+        var = engine.Plan(fmt, 21_000_000, n, **(dict(tile_hint=hint) if hint else {}), **kw)
+        assert var.info.kernel_flags == 164128 and var.info.threads == 1024 and ref.n_windows % var.info.tile_windows != 0
+        a = torch.empty(ref.n_windows, 64, dtype=torch.float32, device=dev)
+        b = torch.zeros_like(a)
+        ref.run_device(src, a)
+        for _ in range(2):
+            b.zero_()
+            var.run_device(src, b)
+            torch.cuda.synchronize()
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), fmt
+        # a sub-range whose first window sits on the row grid (window 4096 * k: 4096 * 512 samples) and whose length is odd
+        w0, nw = 8192, 100_001
+        b.zero_()
+        var.run_device(src, b[w0:w0 + nw], first_window=w0, n_windows=nw)
+        torch.cuda.synchronize()
+        assert torch.equal(a[w0:w0 + nw].view(torch.int32), b[w0:w0 + nw].view(torch.int32)), fmt
+        assert not b[:w0].any() and not b[w0 + nw:].any()
+        var.close(); ref.close()
+        del src, a, b
 
 
 def test_three_stage_kernel_with_the_tile_queue(engine):
