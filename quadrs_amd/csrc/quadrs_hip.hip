@@ -1451,6 +1451,16 @@ int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint6
     uint64_t cw = target_bytes / (step * bps ? step * bps : 1);
     if (cw < p->geo.G) cw = p->geo.G;
     cw = (cw / p->geo.G) * p->geo.G;
+    if ((p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed)) {
+        // row-aligned kernels: a launch whose first window is off the row grid goes to the per-sample kernel (launch_chain), so
+        // chunks start on windows that are multiples of lcm(G, ROW / gcd(ROW, S D))
+        const uint64_t ROW = (uint64_t)p->nt * spl_of(p->d.format);
+        uint64_t a = ROW, b = step % ROW; while (b) { const uint64_t t = a % b; a = b; b = t; }
+        const uint64_t wa = ROW / a;                                    // windows per row-grid period
+        uint64_t g = p->geo.G, h = wa; while (h) { const uint64_t t = g % h; g = h; h = t; }
+        const uint64_t unit = (uint64_t)p->geo.G / g * wa;              // lcm
+        if (first_window % wa == 0 && cw >= unit) cw = (cw / unit) * unit;
+    }
     if (cw > n_windows) cw = n_windows ? n_windows : 1;
     const size_t in_bytes = (size_t)(((cw - 1) * step + rpw + 8) * bps), ob = (size_t)(cw * obw);
     const bool stage_in = src_mem == QD_MEM_HOST, stage_out = out_mem == QD_MEM_HOST;
