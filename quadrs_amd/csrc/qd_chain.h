@@ -113,6 +113,8 @@ struct ChainParams {
     uint32_t a1, b1;           // c + T_fast = a1*D + b1
     uint32_t base_len, log_base, layers;   // rustfft Radix4 plan: W = base_len * 4^layers
     uint32_t lds_raw_elems;    // float2 capacity of the raw tile
+    uint32_t lds_dyn;          // dynamic LDS bytes of this launch: the kernels with a layout of their own (three-stage kernels) check it
+                               // against their compile-time need and do nothing if the host's restatement of the layout fell short
 };
 
 // ---------------------------------------------------------------- geometry policies
@@ -2790,6 +2792,8 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
     float2 *fbx = trc + DR;
     float2 *twl = fbx + (size_t)G * W;
     float *tapl = reinterpret_cast<float *>(twl + W);
+    constexpr uint32_t kLdsNeed = (K::RAW_ELEMS + 2 * DR + G * W + W) * 8 + ((T + 3) & ~3u) * 4;
+    if (P.lds_dyn < kLdsNeed) return;                                              // host / kernel layout disagreement: leave the output untouched (the parity tests see it)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);

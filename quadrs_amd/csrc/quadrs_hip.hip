@@ -824,6 +824,7 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         // dynamic tile queue for the main launch (static strided walk for the short unaligned tail and for tiny grids)
         P.work = nullptr;
         if (part == 0 && (grid & 7u) == 0 && n_tiles >= 4ull * grid) { rc = ensure_work(tabs); if (rc) return rc; P.work = tabs->work; }
+        P.lds_dyn = (uint32_t)(part == 0 && p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes);
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
             void *args[] = {&P};
             HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->launch_nt, 1, 1, (unsigned)(p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes), st, args, nullptr));
