@@ -215,6 +215,19 @@ int main() {
     run<FIR1>(d, stream, &floor_w);
     run<FIR2>(d, stream, &floor_w);
     run<HBM>(d, stream, &floor_w);
+    {   // the same stream out of memory with other allocation attributes (does the path through L2 / the Infinity Cache cost less?)
+        f4 *unc = nullptr, *fine = nullptr;
+        if (hipExtMallocWithFlags((void **)&unc, (size_t)1 << 30, hipDeviceMallocUncached) == hipSuccess && unc) {
+            hipMemset(unc, 0, (size_t)1 << 30);
+            printf("[hipDeviceMallocUncached] "); run<HBM>(d, unc, &floor_w);
+            hipFree(unc);
+        } else printf("hipDeviceMallocUncached: allocation failed\n");
+        if (hipExtMallocWithFlags((void **)&fine, (size_t)1 << 30, hipDeviceMallocFinegrained) == hipSuccess && fine) {
+            hipMemset(fine, 0, (size_t)1 << 30);
+            printf("[hipDeviceMallocFinegrained] "); run<HBM>(d, fine, &floor_w);
+            hipFree(fine);
+        } else printf("hipDeviceMallocFinegrained: allocation failed\n");
+    }
     run<LDS_LIN>(d, stream, &floor_w);
     run<LDS_LANE_ASM>(d, stream, &floor_w);
     run<LDS_LIN_ASM>(d, stream, &floor_w);
