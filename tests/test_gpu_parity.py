@@ -387,7 +387,7 @@ def test_window_subranges_and_slabs_concatenate(engine, oracle, shift, lp, W, S)
         p.run_host(data, p.n_windows - 1, 2)                                            # past the sink's loop
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3p", "cfg4", "cfg3"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3p", "cfg4", "cfg3", "cfg5"])
 def test_full_size_census(engine, oracle, name):
     """EVERY window of the workload at BASELINE.json's full size against the oracle (all host cores, a few seconds): the chains
     without a shift stage must be identical in every bit; with one, all but a handful of windows (an NCO multiplier within
@@ -405,6 +405,10 @@ def test_full_size_census(engine, oracle, name):
         assert nw == 0, (nw, nb, worst, first)                           # no NCO: every bit
     elif name == "cfg3":
         assert nw <= 12 and worst <= 0.2, (nw, nb, worst, first)      # observed: 8 windows on round 2's stream and on round 3's, 0.06-0.12 ulp
+    elif name == "cfg5":
+        # the multi-GPU workload (cf32, 2^31 samples, the streaming kernel with 14-window steps): one rounding-boundary event of the NCO
+        # touches up to W / S = 4 overlapping windows
+        assert nw <= 8 and worst <= 0.5, (nw, nb, worst, first)
     else:
         # 2^27 / 2^31 samples through the NCO: at the observed rate of ~2e-10 rounding-boundary events per sample (cfg3: 2 samples
         # of 8.6e9) the expectation is 0.03 / 0.5 windows.  Round 2's stream had none; round 3's counter-based stream has one in
