@@ -497,7 +497,8 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
         res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
                "outputs_finite": finite, "seams_verified": seams,
                "halo_exchange": None if world == 1 or args.rehearse else {"bytes_per_rank": me.halo * bps, "ms": exchange_ms, "note": "one neighbour send/recv, once per resident slab, outside the timed steps"},
-               "kernel_kind": int(info.kernel_kind), "kernel_flags": int(info.kernel_flags), "tile_windows": int(info.tile_windows), "threads": int(info.threads)}
+               "kernel_kind": int(info.kernel_kind), "kernel_flags": int(info.kernel_flags), "tile_windows": int(info.tile_windows), "threads": int(info.threads),
+               "nco_order": int(nco_order)}
         if with_cpu:
             nwin_cpu = int(min(nw, max(64, (1 << 30) // (info.raw_step * bps))))     # at most 1 GiB of the stream goes to the host
             first, count = plan.src_range(me.w0 + (nw - nwin_cpu) // 2, nwin_cpu)
@@ -712,7 +713,10 @@ def main():
                        "decimate": cfg["lp"][1], "width": cfg["W"], "stride": cfg["S"],
                        "parallelism": f"window-range shards x{world}, halo {(cfg['W'] - cfg['S']) * cfg['lp'][1] + cfg['lp'][2]} samples",
                        "outputs_finite": main_res["outputs_finite"], "kernel_kind": main_res["kernel_kind"], "kernel_flags": main_res["kernel_flags"],
-                       "tile_windows": main_res["tile_windows"], "threads": main_res["threads"]},
+                       "tile_windows": main_res["tile_windows"], "threads": main_res["threads"],
+                       # 1: first-order NCO correction, 2: second-order (streams whose phase n*|ratio| passes 2^28 rad: every multi-rank run of
+                       # 2^31 samples per GPU — the plan describes the WHOLE stream — costs cfg3' 5.6 % per GPU against the one-rank run)
+                       "nco_order": main_res["nco_order"]},
             "roofline": main_res["roofline"],
         }
         if main_res.get("seams_verified") is not None:
