@@ -2768,8 +2768,14 @@ struct Pipe3S {
     static constexpr uint32_t ROWP = (ROW / D) * Dp;                                            // padded elements per row of ROW samples
     static constexpr uint32_t RAW_ELEMS = ((RINGD + MIRD) * Dp + 1) & ~1u;
     static constexpr uint32_t DR = 3 * GS;
-    static constexpr bool ok = GeoT::kShared && GeoT::kUnrolledShared && GS <= 256 && GS >= 1 && N % ROW == 0 && ROW % D == 0 && D % SPL == 0 &&
+    // overlapping windows: the shared FIR keeps a full value AND a truncated snapshot per output (dec + trc); windows side by side
+    // (S == W): every output belongs to one window and keeps the one value that window reads (dec only)
+    static constexpr bool kOverlap = S < W;
+    static constexpr bool fir_ok = kOverlap ? (GeoT::kShared && GeoT::kUnrolledShared)
+                                            : (S == W && GeoT::kPad == 2 && T % 4 == 0 && GeoT::b0 % 2 == 0 && D % 4 == 0 && T / 4 > 3 && (T / 2) % 4 == 0);
+    static constexpr bool ok = fir_ok && GS <= 256 && GS >= 1 && N % ROW == 0 && ROW % D == 0 && D % SPL == 0 &&
                                W <= 64 * 16 && f0 >= 1 && f0 <= GS && f0 > W - S && ntrunc <= S && MIRD * D <= ROW && (G - 1) * S + W <= 2 * GS;
+    static constexpr uint32_t kLdsBytes = (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + G * W + W) * 8 + ((T + 3) & ~3u) * 4;
 };
 
 template <int FMT, int NCO, class GeoT, int RN_, int LB>
@@ -2788,12 +2794,11 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
-    float2 *dec = raw + K::RAW_ELEMS, *trc = dec + DR;
-    float2 *fbx = trc + DR;
+    float2 *dec = raw + K::RAW_ELEMS, *trc = dec + DR;                             // trc exists for overlapping windows only
+    float2 *fbx = dec + (K::kOverlap ? 2u : 1u) * DR;
     float2 *twl = fbx + (size_t)G * W;
     float *tapl = reinterpret_cast<float *>(twl + W);
-    constexpr uint32_t kLdsNeed = (K::RAW_ELEMS + 2 * DR + G * W + W) * 8 + ((T + 3) & ~3u) * 4;
-    if (P.lds_dyn < kLdsNeed) return;                                              // host / kernel layout disagreement: leave the output untouched (the parity tests see it)
+    if (P.lds_dyn < K::kLdsBytes) return;                                              // host / kernel layout disagreement: leave the output untouched (the parity tests see it)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2905,17 +2910,27 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
                 if (l < cnt && !QD_DBG(P, 64)) {
                     const uint32_t q = q_lo + l;                                    // run-local output index
                     uint32_t jmax = T;
-                    if (q + ntrunc >= W) {                                          // may be in the truncated tail of a window of the run
-                        const uint32_t g = (q - (W - ntrunc)) / S, k = q - g * S;
-                        if (k < W) { const uint32_t jm = (W - k) * D + T / 2; if (jm < T) jmax = jm; }
+                    if constexpr (K::kOverlap) {
+                        if (q + ntrunc >= W) {                                      // may be in the truncated tail of a window of the run
+                            const uint32_t g = (q - (W - ntrunc)) / S, k = q - g * S;
+                            if (k < W) { const uint32_t jm = (W - k) * D + T / 2; if (jm < T) jmax = jm; }
+                        }
+                    } else {
+                        const uint32_t k = q & (W - 1);                             // S == W: position in the one window the output belongs to
+                        const uint32_t jm = (W - k) * D + T / 2;
+                        if (jm < T) jmax = jm;
                     }
                     const uint32_t drow = (q + geo.a0) % K::RINGD;
                     const float2 *rowp = raw + (size_t)drow * Dp;
                     float2 snap = make_float2(0.f, 0.f);
                     const float2 full = fir_pair<GeoT, true>(rowp, jmax, tapl, &snap);
                     const uint32_t pos = q % DR;
-                    dec[pos] = full;
-                    if (jmax < T) trc[pos] = snap;
+                    if constexpr (K::kOverlap) {
+                        dec[pos] = full;
+                        if (jmax < T) trc[pos] = snap;
+                    } else {
+                        dec[pos] = jmax < T ? snap : full;
+                    }
                 }
             }
             __syncthreads();
@@ -2940,7 +2955,7 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
                     for (uint32_t o = lane; o < n_o; o += 64) {
                         const uint32_t gl_ = o >> logW, k = o & (W - 1);
                         const uint32_t pos = (q_base + (g0 + gl_) * S + k) % DR;
-                        const bool tr = (W - k) * D + T / 2 < T;
+                        const bool tr = K::kOverlap && (W - k) * D + T / 2 < T;
                         const float2 val = tr ? trc[pos] : dec[pos];
                         const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
                         fbw[(gl_ << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = val;

@@ -321,6 +321,7 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (0, (200_000, 32, 400), 64, 16, 280_000, (14, 512, 1, 8, 4, 2, 1 | (164128 << 8), 0)),    # the built-in cf32 set
     (0, (200_000, 32, 400), 64, 16, 280_000, (6, 512, 1, 8, 4, 2, 1 | (163872 << 8), 0)),     # six-window steps (the smallest the geometry admits here): 96 FIR lanes
     (3, (300_000, 16, 128), 64, 32, None, (4, 512, 1, 8, 4, 2, 1 | (163872 << 8), 0)),        # cs16, no shift
+    (0, (200_000, 32, 200), 128, 128, 280_000, (2, 512, 1, 8, 4, 2, 1 | (164100 << 8), 0)),   # windows side by side (S == W): cfg3's chain through the streaming kernel, no trc ring
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_kernel_variant_flags_equal_generic(engine, oracle, fmt, lp, W, S, shift, hint, epi):
