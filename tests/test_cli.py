@@ -57,6 +57,26 @@ def test_chain_errors_before_any_kernel(cli, tmp_path):
     assert r.returncode == 1 and b"No such file" in r.stderr
 
 
+def test_si_numbers_and_the_minus_rule(cli):
+    """The reference's own unit test for its number parser (src/args.rs:457-465: "123", "1k", "47k", "0M") and the rule that
+    decides whether an argument starting with '-' is an option or a negative number (src/args.rs:420-425: a number only if its
+    THIRD character is a digit — so `shift -50k` and `shift -12` are frequencies, `shift -5k` and `shift -5` are options without a
+    value), through `-parse-only`."""
+    f = os.path.join(GOLDEN, "cupboard-superdec.sr400.cf32")
+    for text, want in (("123", 123), ("1k", 1_000), ("47k", 47_000), ("0M", 0), ("3G", 3_000_000_000)):
+        r = run(cli, "-parse-only", "from", "-sr", text, "-format", "cf32", f)
+        assert r.returncode == 0 and f"sample_rate={want} ".encode() in r.stdout, (text, r.stdout, r.stderr)
+    for text in ("2.5M", "1e3", "1k5", "7m", "5K", "3T", "-5"):                       # u64::from_str fails on all of these (only k / M / G are suffixes)
+        r = run(cli, "-parse-only", "from", "-sr", text, "-format", "cf32", f)
+        assert r.returncode != 0, text
+    for text, want in (("-50k", -50_000), ("-280000", -280_000), ("-12", -12), ("5k", 5_000)):
+        r = run(cli, "-parse-only", "from", "-sr", "1M", "-format", "cf32", f, "shift", text)
+        assert r.returncode == 0 and f"shift {want}\n".encode() in r.stdout, (text, r.stdout, r.stderr)
+    for text in ("-5k", "-5", "-x"):                                                  # taken for an option name: an error, as in the reference
+        r = run(cli, "-parse-only", "from", "-sr", "1M", "-format", "cf32", f, "shift", text)
+        assert r.returncode != 0, text
+
+
 def test_filename_guessing_and_overrides(cli):
     """guess_format_from_name / guess_sample_rate (src/args.rs:100-135, 328-333, 392-402): the `srNNN[kMG]` word, gqrx and rtl_433
     capture names, the extension table, and the -sr / -format overrides (src/args.rs:65-98), through `-parse-only` (nothing is
