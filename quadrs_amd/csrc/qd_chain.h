@@ -2755,9 +2755,10 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3(const ChainPa
 // is the same fir_pair chain over the same shifted samples, computed once instead of up to twice.
 constexpr uint32_t kGeoStream = 131072;
 
-template <int FMT, class GeoT>
+template <int FMT, class GeoT, int PT_ = kPipe3Prod>
 struct Pipe3S {
-    static constexpr uint32_t SPL = FmtTraits<FMT>::SPL, ROW = (uint32_t)kPipe3Prod * SPL;
+    static_assert(PT_ == 256 || PT_ == 512, "producer threads: 256 or 512");
+    static constexpr uint32_t SPL = FmtTraits<FMT>::SPL, ROW = (uint32_t)PT_ * SPL;      // PT_ producer threads (PT_ / 64 waves), then four FIR and four FFT waves
     static constexpr uint32_t W = GeoT::W, S = GeoT::S, D = GeoT::D, T = GeoT::T, G = GeoT::G, Dp = GeoT::Dp;
     static constexpr uint32_t N = G * S * D, RN = N / ROW, GS = G * S;
     static constexpr uint32_t c_half = T - T / 2, ntrunc = c_half ? (c_half + D - 1) / D - 1 : 0;
@@ -2778,15 +2779,15 @@ struct Pipe3S {
     static constexpr uint32_t kLdsBytes = (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + G * W + W) * 8 + ((T + 3) & ~3u) * 4;
 };
 
-template <int FMT, int NCO, class GeoT, int RN_, int LB>
-__global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainParams P) {
+template <int FMT, int NCO, class GeoT, int RN_, int LB, int PT_ = kPipe3Prod>
+__global__ __launch_bounds__(PT_ + 512, LB) void k_chain_pipe3s(const ChainParams P) {
     using FT = FmtTraits<FMT>;
     using Vec = typename FT::Vec;
-    using K = Pipe3S<FMT, GeoT>;
+    using K = Pipe3S<FMT, GeoT, PT_>;
     constexpr int SPL = FT::SPL;
     constexpr bool HAS_SHIFT = NCO != 0;
     static_assert(K::ok && (uint32_t)RN_ == K::RN, "streaming three-stage kernel: geometry");
-    constexpr uint32_t PT = kPipe3Prod;
+    constexpr uint32_t PT = PT_, NTHR = PT_ + 512, PW = PT_ / 64;                    // producer waves [0, PW), FIR waves [PW, PW + 4), FFT waves [PW + 4, PW + 8)
     constexpr uint32_t W = K::W, S = K::S, D = K::D, T = K::T, G = K::G, Dp = K::Dp, logW = GeoT::logW;
     constexpr uint32_t ROW = K::ROW, ROWB = ROW * FT::BPS, VECB = SPL * FT::BPS, RN = K::RN, RR = K::RR, GS = K::GS, DR = K::DR;
     constexpr uint32_t GV = (G + 3) / 4;
@@ -2804,8 +2805,8 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         const uint32_t n_tw = W - geo.base_len;
-        for (uint32_t i = tid; i < n_tw; i += kPipe3Threads) twl[i] = P.tw[i];
-        for (uint32_t i = tid; i < T; i += kPipe3Threads) tapl[i] = P.taps[i];
+        for (uint32_t i = tid; i < n_tw; i += NTHR) twl[i] = P.tw[i];
+        for (uint32_t i = tid; i < T; i += NTHR) tapl[i] = P.taps[i];
     }
     __syncthreads();
 
@@ -2821,7 +2822,7 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
         return left < G ? (uint32_t)left : G;
     };
 
-    if (wave < 8) {
+    if (wave < PW) {
         // ================= producers: step s = it - 1 parks rows [(s + 1) RN, (s + 2) RN) of the run in the ring
         LaneRot lr[SPL];
         if constexpr (HAS_SHIFT) {
@@ -2898,14 +2899,14 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
             __syncthreads();
         }
         if (P.dbg == 0xdeadbeefu) reinterpret_cast<double *>(P.out)[tid] = rt_touch;   // never true: keeps rt_touch live
-    } else if (wave < 12) {
+    } else if (wave < PW + 4) {
         // ================= the shared FIR: step s = it - 2 computes the G S outputs its rows completed (the cold start: f0)
         __builtin_amdgcn_s_setprio(2);
         constexpr uint32_t ntrunc = K::ntrunc;
         for (uint32_t it = 0; it < n_iter; ++it) {
             if (it >= 1 && it <= n_steps + 1) {
                 const uint32_t q_lo = it == 1 ? 0u : K::f0 + (it - 2) * GS, cnt = it == 1 ? K::f0 : GS;
-                uint32_t l = tid - (uint32_t)kPipe3Prod;
+                uint32_t l = tid - PT;
                 asm volatile("" : "+v"(l));
                 if (l < cnt && !QD_DBG(P, 64)) {
                     const uint32_t q = q_lo + l;                                    // run-local output index
@@ -2938,7 +2939,7 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3s(const ChainP
     } else {
         // ================= gather + FFT + |X| of step s = it - 3: wave v takes windows [v GV, (v + 1) GV) of the tile, all wave-local
         __builtin_amdgcn_s_setprio(1);
-        const uint32_t v = wave - 12;
+        const uint32_t v = wave - (PW + 4);
         for (uint32_t it = 0; it < n_iter; ++it) {
             if (it >= 3) {
                 const uint32_t s = it - 3;

@@ -335,11 +335,12 @@ const FixedEntry kFixed[] = {
     { 0, 2, 64, 16, 32, 400, 14, 4, 512, 2, 1, 164128, 7, true, 8, 1,
       qd::k_chain_pipe3s<0, 2, qd::FixedGeo<64, 16, 32, 400, 14, 8, 1, 2, 1, 164128>, 7, 4>, "fsk5" },
 #ifndef QD_DEV_FAST
-    // cs8 input (HackRF) of the same chain: rows of 2048 samples, three per step
-    { 1, 1, 64, 16, 32, 400, 12, 4, 512, 2, 1, 164128, 3, true, 8, 1,
-      qd::k_chain_pipe3s<1, 1, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 164128>, 3, 4>, "cfg3" },
-    { 1, 2, 64, 16, 32, 400, 12, 4, 512, 2, 1, 164128, 3, true, 8, 1,
-      qd::k_chain_pipe3s<1, 2, qd::FixedGeo<64, 16, 32, 400, 12, 8, 1, 2, 1, 164128>, 3, 4>, "cfg3" },
+    // cs8 input (HackRF) of the same chain: four producer waves (rows of 256 threads x 4 samples = 1024 samples, seven per step) so that
+    // 14-window steps start on row boundaries like the cf32 form's (rows of 2048 samples admit 12 or 16 windows, and 16 do not fit)
+    { 1, 1, 64, 16, 32, 400, 14, 4, 256, 2, 1, 164128, 7, true, 8, 1,
+      qd::k_chain_pipe3s<1, 1, qd::FixedGeo<64, 16, 32, 400, 14, 8, 1, 2, 1, 164128>, 7, 4, 256>, "cfg3" },
+    { 1, 2, 64, 16, 32, 400, 14, 4, 256, 2, 1, 164128, 7, true, 8, 1,
+      qd::k_chain_pipe3s<1, 2, qd::FixedGeo<64, 16, 32, 400, 14, 8, 1, 2, 1, 164128>, 7, 4, 256>, "cfg3" },
 #endif
     // configs[3]  512-tap FIR decimate 8 -> 1024-pt FFT (no shift)
     // 70 KiB tile: one workgroup per CU, so give it 1024 threads (16 waves/CU); 5 rows of 2048 samples
@@ -435,8 +436,8 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     }
     char name[512];
     if ((k.flags & kGeoPipe3) && (k.flags & kGeoStream))       // ... its streaming form: contiguous runs of tiles, state carried in LDS rings
-        snprintf(name, sizeof name, "qd::k_chain_pipe3s<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
-                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb);
+        snprintf(name, sizeof name, "qd::k_chain_pipe3s<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d, %d>", k.fmt, k.nco, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb, k.nt);
     else
     if (k.flags & kGeoPipe3)       // the three-stage kernel for overlapping windows (k_chain_pipe3): 512 producer threads + FIR + FFT waves
         snprintf(name, sizeof name, "qd::k_chain_pipe3<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
@@ -560,7 +561,8 @@ struct Geometry {
 // twiddles | taps | 8-bit LUT | shared-FIR dec/trc | batch bookkeeping.  The generic kernels (interleaved tile, pad 1, batch 1,
 // taps in LDS) run inside the same allocation for the unaligned slab tail, so the size is the larger of the two layouts.
 size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint32_t *raw_elems, uint32_t pad_per_row = 1, uint32_t batch = 1,
-               bool lut8 = true, uint32_t flags = 0, size_t *main_only = nullptr, int stream_spl = 2 /* samples per lane and row load (streaming kernel) */) {
+               bool lut8 = true, uint32_t flags = 0, size_t *main_only = nullptr, int stream_spl = 2 /* samples per lane and row load (streaming kernel) */,
+               int stream_nt = 512 /* its producer threads */) {
     uint64_t tile_raw = (uint64_t)(G - 1) * S * D + W * D + T;
     const uint64_t full_raw = tile_raw;
     if ((flags & kGeoHalfTile) && G == 1 && T > 0 && S >= W) tile_raw = (T - T / 2) + (W / 2 - 1) * D + T;     // FixedGeo::kHalfRaw
@@ -592,7 +594,7 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
     const uint64_t generic_b = gen_elems_of(full_raw) * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + lut_b + shared_fir + 16 + 16;
     if ((flags & kGeoPipe3) && (flags & kGeoStream)) {
         // k_chain_pipe3s (qd_chain.h, Pipe3S): sample ring + mirror | dec + trc rings of 3 G S | G*W FFT buffers | twiddles | taps
-        const uint64_t row = 512ull * stream_spl, n_new = (uint64_t)G * S * D, dp = D + ((D % 2 == 0) ? pad_per_row : 0);
+        const uint64_t row = (uint64_t)stream_nt * stream_spl, n_new = (uint64_t)G * S * D, dp = D + ((D % 2 == 0) ? pad_per_row : 0);
         const uint64_t rr = (2 * n_new + T + 2 * D + row - 1) / row, ringd = rr * (row / D);
         const uint64_t c = T - T / 2, mird = ((c % D) + T + D - 1) / D + 1;
         const uint64_t raw_e = ((ringd + mird) * dp + 1) & ~1ull;
@@ -983,7 +985,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
               (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 262143 &&
-              lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags, nullptr, spl_of(d.format)) <= kLdsMax))
+              lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags, nullptr, spl_of(d.format), (int)t8[1]) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
         tuned = true;
@@ -1043,16 +1045,22 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             const uint32_t g_unit = (uint32_t)(ROW / a);                                              // tiles start on rows when G is a multiple of this
             // (1) the STREAMING form (k_chain_pipe3s): a step adds G S new outputs on G S FIR lanes and G S D new samples; the step with
             // the most outputs that the rings leave room for (the FIR stage is bound by the latency of one wave's pass over the T taps,
-            // so outputs per pass is what counts).  The conditions restate Pipe3S<>::ok (qd_chain.h).
-            uint32_t best_s = 0;
-            for (uint32_t g = g_unit; g >= 1 && g <= 64 && (uint64_t)g * S <= 256; g += g_unit) {
-                const uint64_t n_new = (uint64_t)g * S * D, gs = (uint64_t)g * S;
-                if (n_new < (uint64_t)c_half + T) continue;
-                const uint64_t f0 = (n_new - c_half - T) / D + 1, mird = ((c_half % D) + T + D - 1) / D + 1;
-                if (!(ROW % D == 0 && f0 <= gs && f0 > W - S && mird * D <= ROW && (uint64_t)(g - 1) * S + W <= 2 * gs && n_new / ROW <= 10)) continue;
-                if (lds_for(g, W, S, D, T_lds, nullptr, 2, 1, lut8, kGeoUnrolledFir | kGeoPipe3 | kGeoStream, nullptr, spl) > kLdsMax) break;
-                if (p->n_windows < g) break;
-                best_s = g;
+            // so outputs per pass is what counts).  Rows of 512 producer threads, or of 256 where the shorter row admits a larger step
+            // (the 8-bit formats: four samples per lane).  The conditions restate Pipe3S<>::ok (qd_chain.h).
+            uint32_t best_s = 0; int best_nt = 512;
+            for (int snt : {512, 256}) {
+                const uint64_t SROW = (uint64_t)snt * spl;
+                uint64_t a2 = SROW, b2 = step; while (b2) { const uint64_t t = a2 % b2; a2 = b2; b2 = t; }
+                const uint32_t su = (uint32_t)(SROW / a2);
+                for (uint32_t g = su; g >= 1 && g <= 64 && (uint64_t)g * S <= 256; g += su) {
+                    const uint64_t n_new = (uint64_t)g * S * D, gs = (uint64_t)g * S;
+                    if (n_new < (uint64_t)c_half + T) continue;
+                    const uint64_t f0 = (n_new - c_half - T) / D + 1, mird = ((c_half % D) + T + D - 1) / D + 1;
+                    if (!(SROW % D == 0 && f0 <= gs && f0 > W - S && mird * D <= SROW && (uint64_t)(g - 1) * S + W <= 2 * gs && n_new / SROW <= 10)) continue;
+                    if (lds_for(g, W, S, D, T_lds, nullptr, 2, 1, lut8, kGeoUnrolledFir | kGeoPipe3 | kGeoStream, nullptr, spl, snt) > kLdsMax) break;
+                    if (p->n_windows < g) break;
+                    if (g > best_s) { best_s = g; best_nt = snt; }
+                }
             }
             // (2) the tile-at-a-time three-stage kernel, where the streaming form's geometry fails
             uint32_t best = 0;
@@ -1063,7 +1071,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
                 if (p->n_windows < g) break;
                 best = g;
             }
-            if (best_s) { autosel.valid = true; autosel.G = best_s; autosel.nt = 512; autosel.batch = 1; autosel.flags = kGeoUnrolledFir | kGeoPipe3 | kGeoStream | kGeoNtLoads; }
+            if (best_s) { autosel.valid = true; autosel.G = best_s; autosel.nt = best_nt; autosel.batch = 1; autosel.flags = kGeoUnrolledFir | kGeoPipe3 | kGeoStream | kGeoNtLoads; }
             else if (best) { autosel.valid = true; autosel.G = best; autosel.nt = 512; autosel.batch = 1; autosel.flags = kGeoUnrolledFir | kGeoPipe3; }
         }
     }
@@ -1143,7 +1151,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->geo.G = G;
     p->kflags = kflags;
     p->launch_nt = p->nt + ((kflags & kGeoPipe3) ? 512 : ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0));
-    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main, spl_of(d.format));     // the generic kernels (pad 1, batch 1) fit inside the same allocation
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main, spl_of(d.format), p->nt);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);

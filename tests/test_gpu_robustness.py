@@ -268,7 +268,7 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     if lp and lp[2] >= 8 * lp[1]:
         # long-filter policy (512 threads, one large tile) or, for overlapping windows whose geometry allows, the three-stage kernel
         pipe3 = bool(plans["1"].info.kernel_flags & 32768)
-        assert plans["1"].info.threads == (1024 if pipe3 else 512) and plans["1"].info.tile_windows >= plans["0"].info.tile_windows
+        assert plans["1"].info.threads in ((768, 1024) if pipe3 else (512,)) and plans["1"].info.tile_windows >= plans["0"].info.tile_windows
         assert not pipe3 or S < W, plans["1"].info.kernel_flags
     a, b = plans["0"].run_host(data), plans["1"].run_host(data)
     assert bits_equal(a, b)
@@ -321,6 +321,7 @@ def test_plan_time_specialisation_matches_generic(engine, oracle, monkeypatch, f
     (0, (200_000, 32, 400), 64, 16, 280_000, (14, 512, 1, 8, 4, 2, 1 | (164128 << 8), 0)),    # the built-in cf32 set
     (0, (200_000, 32, 400), 64, 16, 280_000, (6, 512, 1, 8, 4, 2, 1 | (163872 << 8), 0)),     # six-window steps (the smallest the geometry admits here): 96 FIR lanes
     (3, (300_000, 16, 128), 64, 32, None, (4, 512, 1, 8, 4, 2, 1 | (163872 << 8), 0)),        # cs16, no shift
+    (1, (200_000, 32, 400), 64, 16, 280_000, (14, 256, 1, 8, 4, 2, 1 | (164128 << 8), 0)),    # the built-in cs8 set: four producer waves (768 threads), 14-window steps
     (0, (200_000, 32, 200), 128, 128, 280_000, (2, 512, 1, 8, 4, 2, 1 | (164100 << 8), 0)),   # windows side by side (S == W): cfg3's chain through the streaming kernel, no trc ring
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2])
@@ -674,12 +675,12 @@ def test_streaming_three_stage_kernel_long_runs(engine):
     import bench
     dev = torch.device("cuda", 0)
     for fmt, hint in ((1, None), (0, [14, 512, 1, 8, 4, 2, 1 | (164128 << 8), 0])):
-        n = (1 << 26) - (0 if fmt == 1 else 40_000)           # window counts that are no multiple of the step (12 / 14)
+        n = (1 << 26) - 40_000                                # a window count that is no multiple of the step (14)
         src = bench.synth_slab(torch, fmt, 0, n, 0x5EED0002, dev)
         kw = dict(shift_hz=280000, lowpass=(200_000, 32, 400), width=64, stride=16)
         ref = engine.Plan(fmt, 21_000_000, n, kernel_policy=engine.KERNEL_GENERIC, **kw)
         var = engine.Plan(fmt, 21_000_000, n, **(dict(tile_hint=hint) if hint else {}), **kw)
-        assert var.info.kernel_flags == 164128 and var.info.threads == 1024 and ref.n_windows % var.info.tile_windows != 0
+        assert var.info.kernel_flags == 164128 and var.info.threads == (768 if fmt == 1 else 1024) and ref.n_windows % var.info.tile_windows != 0      # cs8: four producer waves
         a = torch.empty(ref.n_windows, 64, dtype=torch.float32, device=dev)
         b = torch.zeros_like(a)
         ref.run_device(src, a)
