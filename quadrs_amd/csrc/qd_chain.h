@@ -2754,6 +2754,9 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3(const ChainPa
 // claimed tile would have to be its predecessor's neighbour).  Products, their order and every rounding are unchanged: output q
 // is the same fir_pair chain over the same shifted samples, computed once instead of up to twice.
 constexpr uint32_t kGeoStream = 131072;
+// bit 18: the streaming kernel as the `write` sink (QD_EPI_CF32_BLOCKS, src/lib.rs:178-213): producers + FIR waves only; the FIR lanes store
+// their decimated outputs themselves (a wave's 64 outputs are 512 contiguous bytes), truncation relative to the read_at block (ChainParams::blk_len)
+constexpr uint32_t kGeoWriteSink = 262144;
 
 template <int FMT, class GeoT, int PT_ = kPipe3Prod>
 struct Pipe3S {
@@ -2776,18 +2779,23 @@ struct Pipe3S {
                                             : (S == W && GeoT::kPad == 2 && T % 4 == 0 && GeoT::b0 % 2 == 0 && D % 4 == 0 && T / 4 > 3 && (T / 2) % 4 == 0);
     static constexpr bool ok = fir_ok && GS <= 256 && GS >= 1 && N % ROW == 0 && ROW % D == 0 && D % SPL == 0 &&
                                W <= 64 * 16 && f0 >= 1 && f0 <= GS && f0 > W - S && ntrunc <= S && MIRD * D <= ROW && (G - 1) * S + W <= 2 * GS;
-    static constexpr uint32_t kLdsBytes = (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + G * W + W) * 8 + ((T + 3) & ~3u) * 4;
+    static constexpr bool kWrite = (GeoT::kFlags & kGeoWriteSink) != 0;          // no FFT stage, no output ring
+    static_assert(!kWrite || !kOverlap, "the write sink's sub-blocks lie side by side");
+    static constexpr uint32_t kLdsBytes = kWrite ? RAW_ELEMS * 8 + ((T + 3) & ~3u) * 4
+                                                 : (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + G * W + W) * 8 + ((T + 3) & ~3u) * 4;
+    static constexpr uint32_t kConsumerThreads = kWrite ? 256u : 512u;
 };
 
 template <int FMT, int NCO, class GeoT, int RN_, int LB, int PT_ = kPipe3Prod>
-__global__ __launch_bounds__(PT_ + 512, LB) void k_chain_pipe3s(const ChainParams P) {
+__global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512), LB) void k_chain_pipe3s(const ChainParams P) {
     using FT = FmtTraits<FMT>;
     using Vec = typename FT::Vec;
     using K = Pipe3S<FMT, GeoT, PT_>;
     constexpr int SPL = FT::SPL;
     constexpr bool HAS_SHIFT = NCO != 0;
     static_assert(K::ok && (uint32_t)RN_ == K::RN, "streaming three-stage kernel: geometry");
-    constexpr uint32_t PT = PT_, NTHR = PT_ + 512, PW = PT_ / 64;                    // producer waves [0, PW), FIR waves [PW, PW + 4), FFT waves [PW + 4, PW + 8)
+    constexpr bool kWrite = K::kWrite;
+    constexpr uint32_t PT = PT_, NTHR = PT_ + K::kConsumerThreads, PW = PT_ / 64;                    // producer waves [0, PW), FIR waves [PW, PW + 4), FFT waves [PW + 4, PW + 8)
     constexpr uint32_t W = K::W, S = K::S, D = K::D, T = K::T, G = K::G, Dp = K::Dp, logW = GeoT::logW;
     constexpr uint32_t ROW = K::ROW, ROWB = ROW * FT::BPS, VECB = SPL * FT::BPS, RN = K::RN, RR = K::RR, GS = K::GS, DR = K::DR;
     constexpr uint32_t GV = (G + 3) / 4;
@@ -2798,14 +2806,16 @@ __global__ __launch_bounds__(PT_ + 512, LB) void k_chain_pipe3s(const ChainParam
     float2 *dec = raw + K::RAW_ELEMS, *trc = dec + DR;                             // trc exists for overlapping windows only
     float2 *fbx = dec + (K::kOverlap ? 2u : 1u) * DR;
     float2 *twl = fbx + (size_t)G * W;
-    float *tapl = reinterpret_cast<float *>(twl + W);
+    float *tapl = reinterpret_cast<float *>(kWrite ? raw + K::RAW_ELEMS : twl + W);  // write sink: sample ring | taps, nothing else
     if (P.lds_dyn < K::kLdsBytes) return;                                              // host / kernel layout disagreement: leave the output untouched (the parity tests see it)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
-        const uint32_t n_tw = W - geo.base_len;
-        for (uint32_t i = tid; i < n_tw; i += NTHR) twl[i] = P.tw[i];
+        if constexpr (!kWrite) {
+            const uint32_t n_tw = W - geo.base_len;
+            for (uint32_t i = tid; i < n_tw; i += NTHR) twl[i] = P.tw[i];
+        }
         for (uint32_t i = tid; i < T; i += NTHR) tapl[i] = P.taps[i];
     }
     __syncthreads();
@@ -2816,7 +2826,7 @@ __global__ __launch_bounds__(PT_ + 512, LB) void k_chain_pipe3s(const ChainParam
     const uint64_t t_lo = (uint64_t)blockIdx.x * base_cnt + (blockIdx.x < rem ? blockIdx.x : rem);
     const uint32_t n_steps = (uint32_t)(base_cnt + (blockIdx.x < rem ? 1u : 0u));
     if (n_steps == 0) return;                                                      // uniform over the workgroup
-    const uint32_t n_iter = n_steps + 3;
+    const uint32_t n_iter = n_steps + (kWrite ? 2u : 3u);
     auto g_cnt_of = [&](uint64_t t) -> uint32_t {
         const uint64_t w0 = t * G, left = P.n_windows - w0;
         return left < G ? (uint32_t)left : G;
@@ -2911,6 +2921,14 @@ __global__ __launch_bounds__(PT_ + 512, LB) void k_chain_pipe3s(const ChainParam
                 if (l < cnt && !QD_DBG(P, 64)) {
                     const uint32_t q = q_lo + l;                                    // run-local output index
                     uint32_t jmax = T;
+                    if constexpr (kWrite) {
+                        // truncation relative to the read_at block of blk_len outputs the sub-block lies in (src/filter.rs:68-83 over
+                        // do_write's blocks); every other output is a full chain, whatever sub-block it ends
+                        const uint64_t sub = P.first_window + t_lo * G + (q >> logW);
+                        const uint32_t kb = ((uint32_t)sub & P.blk_sub_mask) * W + (q & (W - 1));
+                        const uint32_t jm = (P.blk_len - kb) * D + T / 2;
+                        if (jm < T) jmax = jm;
+                    } else
                     if constexpr (K::kOverlap) {
                         if (q + ntrunc >= W) {                                      // may be in the truncated tail of a window of the run
                             const uint32_t g = (q - (W - ntrunc)) / S, k = q - g * S;
@@ -2926,6 +2944,12 @@ __global__ __launch_bounds__(PT_ + 512, LB) void k_chain_pipe3s(const ChainParam
                     float2 snap = make_float2(0.f, 0.f);
                     const float2 full = fir_pair<GeoT, true>(rowp, jmax, tapl, &snap);
                     const uint32_t pos = q % DR;
+                    if constexpr (kWrite) {
+                        // do_write / LowPass::read_at output (src/lib.rs:206-209): the decimated cf32 samples themselves, in stream order
+                        const uint64_t qa = (t_lo * G << logW) + q;                // output index within the launch
+                        if (qa < (P.n_windows << logW))
+                            reinterpret_cast<float2 *>(P.out)[((P.first_window - P.out_window0) << logW) + qa] = jmax < T ? snap : full;
+                    } else
                     if constexpr (K::kOverlap) {
                         dec[pos] = full;
                         if (jmax < T) trc[pos] = snap;
@@ -2936,7 +2960,7 @@ __global__ __launch_bounds__(PT_ + 512, LB) void k_chain_pipe3s(const ChainParam
             }
             __syncthreads();
         }
-    } else {
+    } else if constexpr (!kWrite) {
         // ================= gather + FFT + |X| of step s = it - 3: wave v takes windows [v GV, (v + 1) GV) of the tile, all wave-local
         __builtin_amdgcn_s_setprio(1);
         const uint32_t v = wave - (PW + 4);

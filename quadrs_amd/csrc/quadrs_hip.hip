@@ -598,7 +598,8 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
         const uint64_t rr = (2 * n_new + T + 2 * D + row - 1) / row, ringd = rr * (row / D);
         const uint64_t c = T - T / 2, mird = ((c % D) + T + D - 1) / D + 1;
         const uint64_t raw_e = ((ringd + mird) * dp + 1) & ~1ull;
-        const uint64_t p3 = raw_e * 8 + (S < W ? 2 : 1) * 3 * (uint64_t)G * S * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + 64;      // trc: overlapping windows only
+        const uint64_t p3 = (flags & kGeoWriteSink) ? raw_e * 8 + taps_b + 64      // the write sink: sample ring | taps
+                                                    : raw_e * 8 + (S < W ? 2 : 1) * 3 * (uint64_t)G * S * 8 + (uint64_t)G * W * 8 + W * 8 + taps_b + 64;      // trc: overlapping windows only
         if (main_only) *main_only = (size_t)p3;
         return (size_t)(p3 > generic_b ? p3 : generic_b);
     }
@@ -984,7 +985,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         const uint32_t t8[8] = {h[0], h[1], h[2] ? h[2] : 1u, h[3] ? h[3] : 8u, h[4] ? h[4] : 4u, h[5] ? h[5] : 1u, (h[6] & 0xffu) ? (h[6] & 0xffu) : 1u, h[7]};
         hint_flags = h[6] >> 8;          // bits 8+ of slot 6: kernel variant flags (1 planar LDS tile, 2 taps baked into the code)
         if (!(p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && t8[4] >= 1 && t8[4] <= 8 && t8[0] >= 1 &&
-              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 262143 &&
+              (t8[1] == 256 || t8[1] == 512 || t8[1] == 1024) && (t8[5] == 1 || t8[5] == 2) && t8[6] <= 64 && t8[7] <= 8 && hint_flags <= 524287 &&
               lds_for(t8[0], p->W, p->S, p->D, T_lds, nullptr, t8[5], t8[6], lut8, hint_flags, nullptr, spl_of(d.format), (int)t8[1]) <= kLdsMax))
             return fail(QD_ERR_INVALID, "tile_hint {%u,%u,%u,%u,%u,%u,%u,%u} does not fit this chain", t8[0], t8[1], t8[2], t8[3], t8[4], t8[5], t8[6], t8[7]);
         for (int i = 0; i < 8; ++i) tune[i] = t8[i];
@@ -995,7 +996,9 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // repay the ~0.3 s compile (qd_plan_options.kernel_policy: QD_KERNEL_SPECIALISE always, QD_KERNEL_NO_PLAN_TIME /
     // QD_KERNEL_GENERIC never).
     const uint64_t in_bytes = (uint64_t)d.n_samples * bps_of(d.format);
-    const bool jit_ok = d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME;
+    // (the write sink, QD_EPI_CF32_BLOCKS, has exactly one specialised kernel: the streaming one, chosen further down from the geometry)
+    const bool write_sink = d.epilogue == QD_EPI_CF32_BLOCKS;
+    const bool jit_ok = policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME;
     // a cached build is always used; a NEW build only when forced or when the stream is at least 1 GiB
     const bool may_compile = policy == QD_KERNEL_SPECIALISE || tuned || in_bytes >= (1ull << 30) || d.mode == QD_MODE_FAST;
     uint32_t batch = 1, kflags = 0;    // tiles per FFT batch / variant flags the main kernel is built with (FixedGeo BATCH_, FLAGS_)
@@ -1027,7 +1030,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     struct { bool valid = false; uint32_t G = 1, batch = 1, flags = 0, firr = 1, firb = 8; int nt = kThreads; } autosel;
     // QD_MODE_FAST (qd_chain_desc.mode): the built-in kernels are exact-order; a fused build is the geometry recipe + bit 14, made
     // at plan time whatever the stream's size.  No recipe for the shape (overlapping windows, short filters): the exact kernels.
-    const bool fast_mode = d.mode == QD_MODE_FAST && p->has_fir && jit_ok && !tuned;
+    const bool fast_mode = d.mode == QD_MODE_FAST && p->has_fir && jit_ok && !tuned && !write_sink;
     const FixedEntry *fixed_exact = p->fixed;
     if (fast_mode) p->fixed = nullptr;
     if (jit_ok && !tuned && !p->fixed && p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && p->S < p->W && (uint64_t)p->T >= 8ull * p->D) {
@@ -1108,12 +1111,32 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             }
         }
     }
+    if (jit_ok && write_sink && !tuned && p->has_fir) {
+        // The `write` sink (N1: shift -> lowpass -> decimated cf32 in read_at blocks): the streaming kernel with producers and FIR waves
+        // only — a step is one sub-block of W = min(block, 256) outputs on as many FIR lanes, which store their outputs themselves;
+        // truncation is relative to the block (ChainParams::blk_len).  The conditions restate Pipe3S<>::ok for side-by-side windows.
+        const uint32_t W = p->W, D = p->D, T = p->T, c_half = T - T / 2;
+        const int spl = spl_of(d.format);
+        const bool pk_geo = T % 4 == 0 && (T / 2) % 4 == 0 && T / 4 > 3 && D % 4 == 0 && (c_half % D) % 2 == 0 && D % spl == 0 && is_pow2(W) && W <= 256 &&
+                            p->blk_len % W == 0 && is_pow2(p->blk_subs);
+        for (int snt : {512, 256}) {
+            if (!pk_geo || autosel.valid) break;
+            const uint64_t SROW = (uint64_t)snt * spl, n_new = (uint64_t)W * D;
+            if (n_new % SROW != 0 || SROW % D != 0 || n_new < (uint64_t)c_half + T || n_new / SROW > 10) continue;
+            const uint64_t f0 = (n_new - c_half - T) / D + 1, mird = ((c_half % D) + T + D - 1) / D + 1;
+            if (f0 > W || mird * D > SROW) continue;
+            const uint32_t fl = kGeoNoSplit | kGeoNtLoads | kGeoPipe3 | kGeoStream | kGeoWriteSink;
+            if (lds_for(1, W, W, D, T, nullptr, 2, 1, lut8, fl, nullptr, spl, snt) > kLdsMax ||        // the kernel's own layout (its T, no tile_extra) ...
+                lds_for(1, W, W, D, T_lds, nullptr, 1, 1, lut8) > kLdsMax) continue;                        // ... and the generic kernels' tile for an unaligned tail
+            autosel.valid = true; autosel.G = 1; autosel.nt = snt; autosel.batch = 1; autosel.flags = fl;
+        }
+    }
     if (fast_mode) {
         if (autosel.valid) autosel.flags |= kGeoFastFma;
         else p->fixed = fixed_exact;                                   // nothing to fuse in: the exact built-in kernel, if any
     }
     // the long-filter policy serves overlapping windows (shared FIR) and whatever the packed variants above do not take
-    bool heavy = jit_ok && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D && !autosel.valid;
+    bool heavy = jit_ok && !write_sink && !tuned && !p->fixed && p->has_fir && (uint64_t)p->T >= 8ull * p->D && !autosel.valid;
     int jit_lb = 4, jit_noslp = 0;
     uint32_t pad = 1;              // LDS pad elements per row the main kernel is built with (FixedGeo PAD_)
     if (heavy) {
@@ -1150,8 +1173,14 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     }
     p->geo.G = G;
     p->kflags = kflags;
-    p->launch_nt = p->nt + ((kflags & kGeoPipe3) ? 512 : ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0));
-    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main, spl_of(d.format), p->nt);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
+    p->launch_nt = p->nt + ((kflags & kGeoPipe3) ? ((kflags & kGeoWriteSink) ? 256 : 512) : ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0));
+    p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, (kflags & kGeoWriteSink) ? p->T : T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main, spl_of(d.format), p->nt);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
+    if (kflags & kGeoWriteSink) {      // the streaming write kernel is laid out for T; the generic kernels' tile (an unaligned tail) for T + tile_extra
+        uint32_t re_gen = 0;
+        const size_t gen_b = lds_for(G, p->W, p->S, p->D, T_lds, &re_gen, 1, 1, lut8);
+        if (gen_b > p->geo.lds_bytes) p->geo.lds_bytes = gen_b;
+        raw_elems = re_gen;
+    }
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
@@ -1162,7 +1191,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (!p->fn || !p->fn_unaligned) return fail(QD_ERR_UNSUPPORTED, "no kernel built for this format (QD_DEV_FAST build?)");
     {
         // plan-time specialisation for shapes without a built-in FixedGeo kernel
-        const bool want = !heavy && (tuned || (!p->fixed && jit_ok));
+        const bool want = !heavy && (tuned || (!p->fixed && jit_ok && (!write_sink || auto_variant)));
         if (want) {
             p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad, batch, kflags), &p->jit_note, may_compile, &p->taps_h);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "tile_hint build failed: %s", p->jit_note.c_str());
@@ -1178,7 +1207,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
                 p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &re2, 1, 1, lut8, 0);
                 p->geo.lds_main = p->geo.lds_bytes;
                 p->geo.lds_raw_elems = re2;
-                p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, 0, 1, 1, 0), &p->jit_note, may_compile, &p->taps_h);
+                if (!write_sink) p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, 0, 1, 1, 0), &p->jit_note, may_compile, &p->taps_h);      // (the write sink's only other kernel is the generic one)
             }
         }
         // A built-in straight-line FIR kernel (scalar chains of overlapping-window shapes) re-specialised with the plan's OWN filter

@@ -350,6 +350,15 @@ def test_fused_write_blocks(engine, oracle, fmt, D, T, B, shift):
     bps = {0: 8, 1: 2, 2: 2, 3: 4}[fmt]
     part = p.run_host(data[first * bps:(first + count) * bps], 1, 2, src_first=first)
     assert bits_equal(part, got[B:3 * B])
+    # the plan-time kernel of the write sink (the streaming kernel without an FFT stage, where the geometry admits it) against the
+    # generic one: same bytes, whole stream and sub-range
+    ps = engine.Plan(fmt, 21_000_000, N, shift_hz=shift, lowpass=(500_000, D, T), width=B, epilogue=engine.EPI_CF32_BLOCKS, kernel_policy=engine.KERNEL_SPECIALISE)
+    if D % 4 == 0 and T % 8 == 0 and B >= 256:
+        assert ps.info.kernel_kind == 2 and ps.info.kernel_flags & 262144, (ps.info.kernel_kind, ps.info.kernel_flags)
+    else:
+        assert ps.info.kernel_kind == 0
+    assert bits_equal(ps.run_host(data), got)
+    assert bits_equal(ps.run_host(data[first * bps:(first + count) * bps], 1, 2, src_first=first), got[B:3 * B])
 
 
 @pytest.mark.parametrize("shift,lp,W,S", [(280000, (200_000, 32, 400), 64, 16),          # README FSK chain: shared FIR, straight-line kernel
@@ -385,6 +394,33 @@ def test_window_subranges_and_slabs_concatenate(engine, oracle, shift, lp, W, S)
         p.run_host(x[first + 1:first + count].tobytes(), 11, 50, src_first=first + 1)   # slab misses a sample
     with pytest.raises(engine.QuadrsError):
         p.run_host(data, p.n_windows - 1, 2)                                            # past the sink's loop
+
+
+@pytest.mark.parametrize("fmt,D,T,B", [(0, 32, 200, 4096), (1, 32, 400, 4096), (0, 8, 512, 4096), (3, 16, 40, 1024)])
+def test_write_sink_kernel_long_runs(engine, fmt, D, T, B):
+    """The write sink's plan-time kernel on a device-resident stream long enough for runs of many steps per workgroup (ring wrap-around,
+    uneven runs), whole stream and a block sub-range, against the generic kernel: every byte."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    n = (1 << 25) - 12_345
+    src = bench.synth_slab(torch, fmt, 0, n, 0x5EED0002, dev)
+    kw = dict(shift_hz=280000, lowpass=(200_000, D, T), width=B, epilogue=engine.EPI_CF32_BLOCKS)
+    ref = engine.Plan(fmt, 21_000_000, n, kernel_policy=engine.KERNEL_GENERIC, **kw)
+    var = engine.Plan(fmt, 21_000_000, n, kernel_policy=engine.KERNEL_SPECIALISE, **kw)
+    assert ref.info.kernel_kind == 0 and var.info.kernel_kind == 2 and var.info.kernel_flags & 262144, (var.info.kernel_kind, var.info.kernel_flags)
+    a = torch.empty(ref.n_windows * B, 2, dtype=torch.float32, device=dev)
+    b = torch.zeros_like(a)
+    ref.run_device(src, a)
+    var.run_device(src, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    w0, nw = ref.n_windows // 3, ref.n_windows // 2 + 1
+    b.zero_()
+    var.run_device(src, b[w0 * B:(w0 + nw) * B], first_window=w0, n_windows=nw)
+    torch.cuda.synchronize()
+    assert torch.equal(a[w0 * B:(w0 + nw) * B].view(torch.int32), b[w0 * B:(w0 + nw) * B].view(torch.int32))
+    assert not b[:w0 * B].any() and not b[(w0 + nw) * B:].any()
 
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg3p", "cfg4", "cfg3", "cfg5"])
