@@ -555,6 +555,36 @@ def fast_mode_leg(cfg, device, steps=8):
     return res
 
 
+def write_sink_leg(cfg, device, steps=8):
+    """The `write` sink on the default workload's chain (shift -> lowpass -> decimated cf32 in read_at blocks of 0x1000,
+    src/lib.rs:178-213; informational, never `value`): the streaming kernel without an FFT stage, 8 N / D bytes written."""
+    import torch
+    import quadrs_amd as Q
+    n = cfg["n"]
+    slab = synth_slab(torch, cfg["fmt"], 0, n, STREAM_SEED, device)
+    p = Q.Plan(cfg["fmt"], cfg["sr"], n, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=4096, epilogue=Q.EPI_CF32_BLOCKS)
+    out = torch.empty(p.n_windows * 4096, 2, dtype=torch.float32, device=device)
+    for _ in range(3):
+        p.run_device(slab, out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        p.run_device(slab, out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    in_b, out_b = n * BPS[cfg["fmt"]], out.numel() * 4
+    res = {"chain": f"shift {cfg['shift']} -> lowpass -power {cfg['lp'][2] // 2} -decimate {cfg['lp'][1]} {cfg['lp'][0]} -> write (blocks of 4096)",
+           "kernel_kind": int(p.info.kernel_kind), "kernel_flags": int(p.info.kernel_flags), "threads": int(p.info.threads), "ms_per_step": ms, "steps": steps,
+           "value": n / (ms * 1e-3) / 1e6, "unit": "Msamples/s", "read_GBps": in_b / (ms * 1e-3) / 1e9, "written_GBps": out_b / (ms * 1e-3) / 1e9,
+           "hbm_frac": (in_b + out_b) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "outputs_finite": bool(torch.isfinite(out).all().item())}
+    p.close()
+    del slab, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def end_to_end_host(device):
     """Host-resident cfg2 (1 GiB cf32 in host memory -> norms in host memory) through qd_plan_run's chunked, double-buffered
     path: PCIe-inclusive, reported beside the kernel figures, never as `value`.  Pinned buffers (QD_MEM_HOST_PINNED) are the
@@ -733,6 +763,11 @@ def main():
                 line["fast_mode"] = fast_mode_leg(cfg, device)
             except Exception as e:                       # informational leg: never takes the bench line down
                 line["fast_mode"] = {"error": str(e)[:200]}
+        if world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_others:
+            try:
+                line["write_sink"] = write_sink_leg(cfg, device)
+            except Exception as e:                       # informational leg
+                line["write_sink"] = {"error": str(e)[:200]}
         if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
             try:
                 line["end_to_end"] = end_to_end_host(device)
