@@ -1165,6 +1165,10 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     } else {
         while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
         while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
+        // chains without a lowpass (every sample is an FFT input), windows of 128 points and more: 2048 samples per tile while four
+        // workgroups still share a CU — fewer barriers per sample (16 GiB cf32, profiles/r03/nofir_rate.log: W = 128 7.16 -> 6.74 ms,
+        // W = 256 10.50 -> 9.57, cs16 W = 512 10.18 -> 9.07; 4096 samples per tile: 9.04 at W = 128; W = 64 loses with 32 windows: 8.23 -> 9.65)
+        if (!p->has_fir && p->S >= p->W && p->W >= 128) while (G < 64 && (uint64_t)G * p->W < 2048 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
         if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
         if (autosel.valid) {
             G = autosel.G; p->nt = autosel.nt; jit_lb = 4; pad = 2; batch = autosel.batch; kflags = autosel.flags; tune[2] = autosel.firr; tune[3] = autosel.firb;
