@@ -330,7 +330,9 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
     n_total = cfg["n"] * world                       # weak scaling: one slab per GPU
     plan = Q.Plan(fmt, cfg["sr"], n_total, shift_hz=cfg["shift"], lowpass=cfg["lp"], width=cfg["W"], stride=cfg["S"])
     info = plan.info
-    shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, info.tile_windows)
+    # one tiling for every rank's shard table: rank 0's (a rank whose plan obtained another kernel fails here, not in the exchange)
+    tile_w = SH.agree_tile_windows(int(info.tile_windows), dist, torch, "cpu" if (dist is None or args.rehearse) else device)
+    shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, tile_w)
     me = shards[rank]
 
     # ONE pre-sized buffer per rank: own samples first, room for the halo behind them; the generator writes into it and the

@@ -72,6 +72,9 @@ def lib():
             "qo_blackman_harris": (None, [sz, vp]),
             "qo_take_fft": (i32, [vp, i32, u64, u64, sz, i32, sz, vp, vp]),
             "qo_do_write": (i32, [vp, vp, u64, vp]),
+            "qo_norm_batch": (None, [vp, sz, vp]),
+            "qo_device_norm_model": (f32, [f32, f32, i32, vp]),
+            "qo_device_norm_selftest": (u64, [u64, u64, i32, i32, i32, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -279,12 +282,7 @@ def dft_f64(x):
 
 
 def norm(x):
-    x = as_c32(x)
+    x = np.ascontiguousarray(as_c32(x))
     out = np.empty(x.shape[0], dtype=np.float32)
-    # hypotf per element through the same libm the oracle links
-    h = C.CDLL("libm.so.6").hypotf
-    h.restype = C.c_float
-    h.argtypes = [C.c_float, C.c_float]
-    for i in range(x.shape[0]):
-        out[i] = h(float(x[i, 0]), float(x[i, 1]))
+    lib().qo_norm_batch(_p(x), x.shape[0], _p(out))      # hypotf per element through the same libm the oracle links
     return out

@@ -83,6 +83,69 @@ static inline qo_c32 c_scale(qo_c32 a, float s) { qo_c32 r = { a.re * s, a.im * 
 
 /* num-complex norm() = re.hypot(im) -> libm hypotf (src/fft.rs:53, src/ffts.rs:77) */
 float qo_norm(qo_c32 v) { return hypotf(v.re, v.im); }
+/* the same over an array (test helper: the device's |X| against the libm the reference links, src/fft.rs:53) */
+void qo_norm_batch(const qo_c32 *v, size_t n, float *out) { for (size_t i = 0; i < n; i++) out[i] = hypotf(v[i].re, v[i].im); }
+
+/*
+ * Model of the DEVICE's |X| (quadrs_amd/csrc/qd_device.h, norm_ref) — not reference code: a CPU restatement of the engine's own
+ * short form, so that its claim "equal to glibc hypotf for every input" is checked where 10^9 pairs cost seconds.
+ * glibc 2.35 __hypotf is (float)sqrt((double)x*x + (double)y*y) (inf / nan screened first).  The device computes s the same way,
+ * then, instead of an IEEE f64 sqrt (~20 f64-rate instructions), takes r = sf * rsq(sf) with sf = (float)s (about 22 good bits),
+ * ONE Newton step in f64, g = r + (s - r*r) * (0.5 * rsq), whose distance from sqrt(s) is bounded by 2^-43.4 sqrt(s), and returns
+ * (float)g UNLESS g lies within 2^12 f64-ulps of an f32 rounding boundary (the low 29 mantissa bits near 0x10000000) or s is outside
+ * [2^-96, 2^96): then the IEEE form runs.  Away from a boundary g, sqrt(s) and RN64(sqrt(s)) round to the same f32, so the result
+ * equals the reference's including ITS double rounding.  `q_ulps` perturbs the model's reciprocal square root by that many f32
+ * ulps: the hardware instruction (v_rsq_f32) is accurate to 1 ulp, and the proof must hold for any such value.
+ * returns the model's result; *slow = 1 when the IEEE path was taken.
+ */
+float qo_device_norm_model(float x, float y, int q_ulps, int *slow) {
+    union { double d; uint64_t u; } S, G;
+    const double dx = (double)x, dy = (double)y;
+    S.d = dx * dx + dy * dy;
+    if (slow) *slow = 0;
+    const uint32_t hi = (uint32_t)(S.u >> 32);
+    const int in_range = (uint32_t)(hi - ((1023u - 96u) << 20)) < (192u << 20);
+    if (in_range) {
+        const float sf = (float)S.d;
+        union { float f; uint32_t u; } Q;
+        Q.f = (float)(1.0 / sqrt((double)sf));
+        Q.u += (uint32_t)q_ulps;                               /* any value within the instruction's accuracy */
+        const float r = sf * Q.f, qh = 0.5f * Q.f;
+        const double rd = (double)r;
+        const double e = fma(-rd, rd, S.d);
+        G.d = fma(e, (double)qh, rd);
+        const uint32_t m = ((uint32_t)G.u & 0x1fffffffu) - (0x10000000u - 4096u);
+        if (m >= 8192u) return (float)G.d;
+    }
+    if (slow) *slow = 1;
+    if (!(isfinite(x) && isfinite(y))) {
+        if (isinf(x) || isinf(y)) return INFINITY;
+        return x + y;
+    }
+    return (float)sqrt(S.d);
+}
+
+/* n pseudo-random pairs (splitmix64; exponents spread over `spread` binades around 1.0, mode 1: both components of similar
+ * size, mode 0: independent) through the model and through hypotf: mismatches and slow-path count */
+static uint64_t qo_sm64(uint64_t *st) { uint64_t z = (*st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+uint64_t qo_device_norm_selftest(uint64_t n, uint64_t seed, int spread, int mode, int q_ulps, uint64_t *n_slow) {
+    uint64_t st = seed, bad = 0, slow_n = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t h = qo_sm64(&st), h2 = qo_sm64(&st);
+        union { float f; uint32_t u; } X, Y, A, B;
+        const int ex = 127 + (int)((h >> 40) % (uint64_t)(2 * spread + 1)) - spread;
+        const int ey = mode ? ex + (int)((h2 >> 40) % 5u) - 2 : 127 + (int)((h2 >> 40) % (uint64_t)(2 * spread + 1)) - spread;
+        X.u = ((uint32_t)(h >> 63) << 31) | ((uint32_t)(ex < 1 ? 1 : (ex > 254 ? 254 : ex)) << 23) | ((uint32_t)h & 0x7fffffu);
+        Y.u = ((uint32_t)(h2 >> 63) << 31) | ((uint32_t)(ey < 1 ? 1 : (ey > 254 ? 254 : ey)) << 23) | ((uint32_t)h2 & 0x7fffffu);
+        int sl = 0;
+        A.f = qo_device_norm_model(X.f, Y.f, q_ulps, &sl);
+        B.f = hypotf(X.f, Y.f);
+        slow_n += (uint64_t)sl;
+        if (A.u != B.u) bad++;
+    }
+    if (n_slow) *n_slow = slow_n;
+    return bad;
+}
 
 /* ------------------------------------------------------------------ A3: shift */
 

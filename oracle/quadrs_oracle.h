@@ -124,6 +124,11 @@ int      qo_do_write(const qo_node *n, qo_c32 *out, uint64_t cap, uint64_t *n_wr
 
 /* hypotf as the reference calls it (num-complex norm() -> f32::hypot -> libm hypotf) */
 float    qo_norm(qo_c32 v);
+void     qo_norm_batch(const qo_c32 *v, size_t n, float *out);
+/* NOT reference code: CPU model of the device's short-form |X| (qd_device.h norm_ref) and its self-test against hypotf;
+ * see quadrs_oracle.c */
+float    qo_device_norm_model(float x, float y, int q_ulps, int *slow);
+uint64_t qo_device_norm_selftest(uint64_t n, uint64_t seed, int spread, int mode, int q_ulps, uint64_t *n_slow);
 
 #ifdef __cplusplus
 }

@@ -1233,7 +1233,7 @@ __device__ __forceinline__ float2 fir_prefix(const float2 *raw, uint32_t t0, uin
 // One wave transforms a parked tile (pg windows at fbp, FIR output in rustfft's digit-reversed order) and writes its output:
 // LDS operations of one wave execute in order, so the passes are separated by a compiler-level fence only.  twl = the layer
 // twiddles (LDS or global), pw0 = the tile's first window.
-template <class GeoT>
+template <class GeoT, uint32_t KB = 0 /* bucket epilogue: bins per lane the caller's buffer may hold (0: from the geometry) */>
 __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const GeoT &geo, const float2 *twl, float2 *fbp, uint64_t pw0, uint32_t pg, uint32_t tid) {
     uint32_t lane = tid & 63u;
     asm volatile("" : "+v"(lane));            // opaque: per-lane LDS / output addresses are rebuilt per tile, not hoisted out of the tile loop and spilled
@@ -1291,7 +1291,7 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
     if (P.epi == 2) {
         // freq_levels: the norms replace the transformed samples in place (every lane reads its share first), then one lane
         // per window forms the two sequential half sums (src/fft.rs:95-97)
-        constexpr uint32_t K = GeoT::kFixed ? (GeoT::G_ct * GeoT::W_ct + 63) / 64 : 1;
+        constexpr uint32_t K = KB ? KB : (GeoT::kFixed ? (GeoT::G_ct * GeoT::W_ct + 63) / 64 : 1);
         float nm[K];
 #pragma unroll
         for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; nm[k] = o < n_out_s ? norm_ref(fbp[o]) : 0.f; }
@@ -1300,12 +1300,12 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
 #pragma unroll
         for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; if (o < n_out_s) nb[o] = nm[k]; }
         wsync();
-        if (lane < pg) {
-            const float *q = nb + (lane << geo.logW);
+        for (uint32_t wl = lane; wl < pg; wl += 64) {                       // (more than 64 windows per buffer: the wave-local kernel at W < 16)
+            const float *q = nb + (wl << geo.logW);
             float first = 0.f, second = 0.f;
             for (uint32_t k = 0; k < geo.W / 2; ++k) first = first + q[k];
             for (uint32_t k = geo.W / 2; k < geo.W; ++k) second = second + q[k];
-            reinterpret_cast<uint8_t *>(P.out)[wrel + lane] = first < second ? 0 : 1;
+            reinterpret_cast<uint8_t *>(P.out)[wrel + wl] = first < second ? 0 : 1;
         }
     } else {
         float *outf = reinterpret_cast<float *>(P.out) + (wrel << geo.logW);
@@ -1595,11 +1595,13 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
         unsigned long long claim = 0;
         if (dyn && tid == 0 && (!kHalf || half == 1)) claim = atomicAdd(&P.work[16 * my_x], 1ull);     // the tile after next; the reply is read after the FIR
         if constexpr (kFastP1) {
-            // Row-aligned tiles (S*D a multiple of the row length, the tile a compile-time number of rows, full tiles only — the
-            // host sends a short last tile to the per-sample kernel): every row offset is an immediate, the loads go through a
-            // per-tile buffer descriptor whose hardware range check replaces the clamp arithmetic (a vector past the slab's end
-            // reads as zero and is never used), interior rows carry no bounds logic and only the last row is predicated, with a
-            // compile-time extent.  ~250 fewer scalar / vector instructions per tile and wave than the general path below.
+            // Row-aligned tiles (the tile stride G*S*D a multiple of the row length, the tile a compile-time number of rows): every row
+            // offset is an immediate, the loads go through a per-tile buffer descriptor whose hardware range check replaces the clamp
+            // arithmetic (a vector past the slab's end reads as zero and is never used), interior rows carry no bounds logic and only
+            // the last row is predicated, with a compile-time extent.  A SHORT last tile (n_windows not a multiple of G) runs in the
+            // same launch: it loads and parks the full row count (the descriptor covers the slab end, the host extends the row table
+            // by one tile) and the FIR / epilogue are bounded by g_cnt.  ~250 fewer scalar / vector instructions per tile and wave
+            // than the general path below.
             constexpr uint32_t ROWB = NT * SPL * FT::BPS, VECB = SPL * FT::BPS;
             constexpr uint32_t kTileRaw = kHalf ? GeoT::kHalfRaw : (GeoT::G - 1) * GeoT::S * GeoT::D + GeoT::W * GeoT::D + GeoT::T;
             constexpr uint32_t kRem = kTileRaw - (RCH - 1) * (NT * SPL);          // samples in the last row
@@ -2994,5 +2996,177 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
         }
     }
 }
+
+// ---------------------------------------------------------------- chains WITHOUT a lowpass: the wave-local kernel (FLAGS bit 19)
+//
+// `from F [shift] sparkfft` (README example 1, BASELINE configs[0]; src/fft.rs:28-65 straight over Shift / SampleFile): every input
+// sample is an FFT input, windows lie side by side (stride == width), so a window is a pure function of W consecutive samples and
+// nothing is shared between windows at all.  k_chain serves that shape with its tile machinery — phase 1 into a raw tile, a barrier,
+// a gather into transform order, a barrier, the base butterflies, a barrier per Radix4 layer, the epilogue — and runs at the SUM of
+// its HBM time and its arithmetic time (16 GiB cf32, W = 128: 6.7 ms where either alone is ~3; profiles/r03/nofir_rate.log).
+// Here a WAVE owns a tile of TS = NCH * 64 * SPL consecutive samples (1024 for every format: G = 1024 / W windows) from load to
+// store, and no workgroup barrier exists after the prologue:
+//   * one coalesced row load per chunk (64 lanes x 16 B, or x 8 B for the 8-bit formats), the NEXT tile's chunks prefetched into
+//     the registers the current ones vacate (non-temporal: every byte is read once), through a per-tile buffer descriptor whose
+//     range check covers the slab end and a short last tile;
+//   * unpack and NCO multiply as in k_chain (same process arithmetic: nco_mul_n, cmul_pk, the reciprocal unpack), the shifted
+//     sample written STRAIGHT to its place in rustfft's transposed input order (bitreversed_transpose) in the wave's own LDS slice —
+//     there is no raw tile and no gather pass;
+//   * the Radix4 passes, |X| and the epilogue wave-local (wave_fft_epilogue_fn: LDS operations of one wave execute in order, the
+//     passes are separated by compiler-level fences); with 1024 samples per tile the base butterflies fill every lane for W >= 16.
+// Sixteen independent waves per CU, each with its next tile (8 KiB cf32) in flight, hide the HBM latency that k_chain's four
+// workgroups hid with a tile of prefetch behind a chain of barriers.  Products, order and roundings are k_chain's, so the output
+// is bit-identical to the generic kernel's (tests/test_gpu_robustness.py::test_wave_local_kernel_equals_generic) and to the oracle.
+// NCO row geometry: rows of 512 samples for every format (ChainParams::rowtab, jtab with 512 entries); a tile is two rows, a chunk
+// the quarter (cf32) or half (8-bit, cs16) of a row, so the lane constants of chunk c are those of quarter c % RQ: RQ * SPL = 8
+// (cos, sin) pairs per lane, kept in registers.
+constexpr uint32_t kGeoSpark = 524288;       // FLAGS bit 19 (reported in qd_plan_info.kernel_flags)
+constexpr uint32_t kSparkRow = 512;          // samples per NCO row of this kernel, every format
+constexpr uint32_t kSparkMaxW = 1024;
+
+template <int FMT> struct SparkTraits {
+    using FT = FmtTraits<FMT>;
+    static constexpr uint32_t SPL = FT::SPL, CH = 64u * SPL, RQ = kSparkRow / CH;       // chunk: one wave-wide load; RQ chunks per NCO row
+};
+
+template <int FMT, int NCO, class GeoT, int NCH, int LB>
+__global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
+    using FT = FmtTraits<FMT>;
+    using Vec = typename FT::Vec;
+    using ST = SparkTraits<FMT>;
+    constexpr int SPL = FT::SPL;
+    constexpr bool HAS_SHIFT = NCO != 0;
+    constexpr uint32_t CH = ST::CH, RQ = ST::RQ, TS = (uint32_t)NCH * CH, CHB = CH * FT::BPS, VECB = SPL * FT::BPS;
+    static_assert(TS % kSparkRow == 0 && (NCH % RQ) == 0, "a tile is a whole number of NCO rows");
+    const GeoT geo(P);
+    const uint32_t W = geo.W, logW = geo.logW;
+    const uint32_t G = TS >> logW;                                         // windows per tile (host: P.G == G, W <= TS)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *twl = reinterpret_cast<float2 *>(smem);                        // radix-4 layer twiddles (< W entries), shared by the four waves
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *fbw = twl + (W < 16u ? 16u : W) + (size_t)wave * TS;           // this wave's transform buffer: TS complex samples
+    {
+        const uint32_t n_tw = W - geo.base_len;
+        for (uint32_t i = tid; i < n_tw; i += kThreads) twl[i] = P.tw[i];
+    }
+    __syncthreads();                                                       // the only workgroup barrier
+
+    // per-lane constants: where each of the lane's NCH * SPL samples of a tile goes (bitreversed_transpose::<4>(base_len, ..):
+    // out[y + rev(x) * base] = in[x + y * width]), and the NCO lane rotations of the RQ row quarters
+    uint32_t pos[NCH * SPL];
+    {
+        const uint32_t log_width = 2 * geo.layers;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                const uint32_t m = (uint32_t)c * CH + lane * SPL + (uint32_t)u, k = m & (W - 1);
+                const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                pos[c * SPL + u] = (m & ~(W - 1)) + yy + (rev4(xx, geo.layers) << geo.log_base);
+            }
+    }
+    // (cos, sin)(j * ratio) of the lane's sample slots in each row quarter; the slot index itself is kept for quarter 0 only — the
+    // quarter's offset q * CH goes into the row's sample count instead (integers below 2^53: the same double whichever way they add up)
+    double2 lcs[HAS_SHIFT ? RQ * SPL : 1];
+    double ljf[HAS_SHIFT ? SPL : 1];
+    if constexpr (HAS_SHIFT) {
+#pragma unroll
+        for (uint32_t q = 0; q < RQ; ++q)
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) lcs[q * SPL + u] = P.jtab[q * CH + lane * SPL + (uint32_t)u];
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) ljf[u] = (double)(lane * SPL + (uint32_t)u);
+    }
+
+    const uint64_t n_tiles = (P.n_windows + G - 1) / G;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kThreads / 64);
+    uint64_t tile = (uint64_t)blockIdx.x * (kThreads / 64) + wave;
+    if (tile >= n_tiles) return;                                           // (after the barrier; wave-uniform)
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    auto rsrc_of = [&](uint64_t t) {
+        const uint64_t ns = (P.first_window + t * G) << logW, end = P.src_first + P.src_count;
+        const uint64_t left = ns < end ? (end - ns) * FT::BPS : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * FT::BPS, 0,
+                                                 left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
+    };
+    Vec pf[NCH];
+    auto load_chunk = [&](const decltype(rsrc_of(0)) &rsrc, int c) {
+        constexpr int aux = 2;                                             // nt: the stream is read once
+        if constexpr (sizeof(Vec) == 16) {
+            const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * VECB), (int)(c * CHB), aux);
+            pf[c].x = w.x; pf[c].y = w.y; pf[c].z = w.z; pf[c].w = w.w;
+        } else {
+            const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(lane * VECB), (int)(c * CHB), aux);
+            pf[c].x = w.x; pf[c].y = w.y;
+        }
+    };
+    {
+        const auto rsrc = rsrc_of(tile);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) load_chunk(rsrc, c);
+    }
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    while (true) {
+        const uint64_t tile_n = tile + n_waves;
+        const auto rsrc_n = rsrc_of(tile_n < n_tiles ? tile_n : tile);      // last tile of this wave: harmless re-loads
+        const uint64_t w0 = P.first_window + tile * G, left_w = P.first_window + P.n_windows - w0;
+        const uint32_t g_cnt = left_w < G ? (uint32_t)left_w : G;
+        const_f64_p rows = nullptr;
+        if constexpr (HAS_SHIFT) rows = (const_f64_p)(uintptr_t)(P.rowtab + (((w0 << logW) / kSparkRow) - P.rowtab_row0));
+        RowBase rb{};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const Vec v = pf[c];
+            if constexpr (HAS_SHIFT) { if (c % (int)RQ == 0) rb = load_rowbase_at(rows, c / (int)RQ); }
+            float2 x[SPL];
+            if constexpr (FMT == 0) {
+                x[0] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+                x[1] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
+            } else if constexpr (FMT == 1) {
+                const uint32_t a = v.x ^ 0x80808080u, b = v.y ^ 0x80808080u;
+                x[0] = make_float2(unpack_cs8_at(a, 0), unpack_cs8_at(a, 1));
+                x[1] = make_float2(unpack_cs8_at(a, 2), unpack_cs8_at(a, 3));
+                x[2] = make_float2(unpack_cs8_at(b, 0), unpack_cs8_at(b, 1));
+                x[3] = make_float2(unpack_cs8_at(b, 2), unpack_cs8_at(b, 3));
+            } else if constexpr (FMT == 2) {
+                x[0] = make_float2(unpack_cu8_at(v.x, 0), unpack_cu8_at(v.x, 1));
+                x[1] = make_float2(unpack_cu8_at(v.x, 2), unpack_cu8_at(v.x, 3));
+                x[2] = make_float2(unpack_cu8_at(v.y, 0), unpack_cu8_at(v.y, 1));
+                x[3] = make_float2(unpack_cu8_at(v.y, 2), unpack_cu8_at(v.y, 3));
+            } else {
+                x[0] = make_float2(unpack_cs16(v.x & 0xffffu), unpack_cs16(v.x >> 16));
+                x[1] = make_float2(unpack_cs16(v.y & 0xffffu), unpack_cs16(v.y >> 16));
+                x[2] = make_float2(unpack_cs16(v.z & 0xffffu), unpack_cs16(v.z >> 16));
+                x[3] = make_float2(unpack_cs16(v.w & 0xffffu), unpack_cs16(v.w >> 16));
+            }
+            if constexpr (HAS_SHIFT) {
+                float2 m[SPL];
+                const int q = c % (int)RQ;
+                LaneRot lr[SPL];
+#pragma unroll
+                for (int u = 0; u < SPL; ++u) { lr[u].jf = ljf[u]; lr[u].c = lcs[q * SPL + u].x; lr[u].s = lcs[q * SPL + u].y; }
+                RowBase rbq = rb;
+                rbq.nf = rb.nf + (double)(q * (int)CH);
+                nco_mul_n<NCO == 2, SPL>(rbq, lr, P.ratio, m);
+#pragma unroll
+                for (int u = 0; u < SPL; ++u) x[u] = cmul_pk(x[u], m[u]);       // buf[i] *= mul (src/shift.rs:51)
+            }
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) fbw[pos[c * SPL + u]] = x[u];
+            __builtin_amdgcn_sched_barrier(0);                              // refill slot c only after chunk c is consumed (see k_chain)
+            load_chunk(rsrc_n, c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wsync();
+        wave_fft_epilogue_fn<GeoT, TS / 64>(P, geo, twl, fbw, w0, g_cnt, tid);
+        wsync();                                                            // the next tile's samples overwrite what the epilogue read
+        if (tile_n >= n_tiles) break;
+        tile = tile_n;
+    }
+}
+
 
 }  // namespace qd

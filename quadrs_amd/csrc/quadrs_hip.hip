@@ -304,6 +304,32 @@ chain_fn pick_generic(int fmt, int nco, bool fir, bool aligned) {
     return nullptr;
 }
 
+// ---- chains without a lowpass, windows side by side: the wave-local kernel (k_spark, qd_chain.h); runtime width, tiles of 1024 samples
+template <int F, int TS>
+chain_fn pick_spark_ts(int nco) {
+    constexpr int NCH = TS / (int)SparkTraits<F>::CH;
+    constexpr int LBS = TS == 512 ? 3 : 2;      // chains with a shift: register budget of three (two) waves per SIMD, see spark_lb
+    switch (nco) {
+    case 0: return k_spark<F, 0, DynGeo, NCH, 4>;
+    case 1: return k_spark<F, 1, DynGeo, NCH, LBS>;
+    default: return k_spark<F, 2, DynGeo, NCH, LBS>;
+    }
+}
+// waves per SIMD the built-in kernel is register-budgeted for (= workgroups per CU): without a shift 128 VGPRs hold everything;
+// with one, the lane constants of the row quarters (16 doubles), the NCO's f64 temporaries and the next tile's prefetch beside the
+// sixteen-point butterflies need ~150 (tiles of 512 samples) / ~190 (1024): budgeted at 4 they spill 9-85 registers to scratch
+int spark_lb(uint32_t ts, int nco) { return nco == 0 ? 4 : (ts == 512 ? 3 : 2); }
+// tile sizes of the built-in (runtime-width) kernels: 1024 samples per wave, which fills the lanes of the sixteen-point base
+// butterflies too; chains WITH a shift take 512 up to W = 512 — their lane constants (16 doubles) and the NCO's f64 temporaries on top
+// of 1024 samples of prefetch do not fit 128 registers (61-85 spilled), with 512 they do
+uint32_t spark_tile(uint32_t W, int nco) { return (nco != 0 && W <= 512) ? 512u : 1024u; }
+chain_fn pick_spark(int fmt, int nco, uint32_t ts) {
+#define QD_X(F) (ts == 512 ? pick_spark_ts<F, 512>(nco) : pick_spark_ts<F, 1024>(nco))
+    switch (fmt) { QD_FMT_CASES(QD_X) }
+#undef QD_X
+    return nullptr;
+}
+
 // ---- shape-specialised kernels (FixedGeo): the chain shapes of BASELINE.json / the README.
 // Same source as the generic kernel with W,S,D,T,G as compile-time constants.
 const FixedEntry kFixed[] = {
@@ -379,6 +405,9 @@ std::mutex g_jit_mu;
 // key).  The on-disk code object is shared, only the load is repeated per device (one-process multi-device plans,
 // qd_plan_options.shard_device[]; that path is unexercised until a multi-GPU box is available — DESIGN.md section 8).
 std::map<std::pair<int, JitKey>, hipFunction_t> g_jit_cache;
+// builds that FAILED in this process (a static_assert of the kernel the host's restatement of its geometry did not foresee, a hiprtc
+// error): remembered with their message, so that every later plan of the shape falls back at once instead of paying the compile again
+std::map<std::pair<int, JitKey>, std::string> g_jit_failed;
 
 std::string csrc_dir() {
     Dl_info info;
@@ -428,6 +457,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     const std::pair<int, JitKey> dk(jit_dev, k);
     auto it = g_jit_cache.find(dk);
     if (it != g_jit_cache.end()) return it->second;
+    if (auto bad = g_jit_failed.find(dk); bad != g_jit_failed.end()) { *why = bad->second; return nullptr; }
     const std::string dir = csrc_dir();
     std::vector<char> hdr1, hdr2;
     if (!read_file(dir + "/qd_chain.h", &hdr1) || !read_file(dir + "/qd_device.h", &hdr2)) {
@@ -435,6 +465,10 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         return nullptr;
     }
     char name[512];
+    if (k.flags & kGeoSpark)       // the wave-local kernel of chains without a lowpass: rch = chunks per tile
+        snprintf(name, sizeof name, "qd::k_spark<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb);
+    else
     if ((k.flags & kGeoPipe3) && (k.flags & kGeoStream))       // ... its streaming form: contiguous runs of tiles, state carried in LDS rings
         snprintf(name, sizeof name, "qd::k_chain_pipe3s<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d, %d>", k.fmt, k.nco, k.W,
                  k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb, k.nt);
@@ -519,6 +553,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
         std::string log(ls, 0); if (ls) hiprtcGetProgramLog(prog, &log[0]);
         *why = "hiprtc: " + log.substr(0, 300);
+        g_jit_failed[dk] = *why;
         hiprtcDestroyProgram(&prog);
         return nullptr;
     }
@@ -658,6 +693,8 @@ struct qd_plan {
     Geometry geo;
     chain_fn fn = nullptr, fn_unaligned = nullptr;
     const FixedEntry *fixed = nullptr;
+    uint32_t spark_ts = 0;               // ... its tile: samples per wave (512 or 1024)
+    bool spark = false;                  // the wave-local kernel of chains without a lowpass (k_spark) is this plan's main kernel
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
     int wg_per_cu = 1, n_cu = 256, prefetch_mode = 2, nco = 0, nt = kThreads;      // nt: threads that share a row of phase 1 (row = nt * SPL samples)
@@ -740,11 +777,13 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
                     (unsigned long long)src_first, (unsigned long long)src_count, (unsigned long long)need0,
                     (unsigned long long)need1, (unsigned long long)first_window, (unsigned long long)n_windows);
     int rc = QD_OK;
-    if (tabs->launched && tabs->last_stream != st) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));      // see NcoTabs
+    // see NcoTabs.  ALWAYS wait: a stream handle compared with the previous caller's may be a new stream at a recycled address (the old one
+    // destroyed with its kernels still running); a wait on an event recorded in the same stream costs nothing
+    if (tabs->launched) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));
     if (p->has_shift) {
         // row-aligned phase 1: rows of a short last tile's missing windows (and a half-window pass's read-ahead) get table entries too
         // (the streaming kernel parks one more step of rows behind a run's last tile)
-        const uint64_t extra = ((p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed)) ? (uint64_t)p->geo.G * p->S * p->D * ((p->kflags & kGeoStream) ? 2 : 1) + p->T : 0;
+        const uint64_t extra = ((p->kflags & (kGeoFastP1 | kGeoPipe3 | kGeoSpark)) && (p->jit_fn || p->fixed || p->spark)) ? (uint64_t)p->geo.G * p->S * p->D * ((p->kflags & kGeoStream) ? 2 : 1) + p->T : 0;
         rc = ensure_rowtab_for(p, p->nt * spl_of(fmt), &tabs->main, need0, need1 + extra, st);
         if (rc) return rc;
     }
@@ -793,7 +832,9 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
                         src_count * (uint64_t)bps >= (uint64_t)vec_bytes;
     uint64_t n_aligned = 0;
     // row-aligned phase 1 with G S D (not S D) a multiple of the row: the launch's first window must sit on a row boundary too
-    const bool fast_misaligned = (p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
+    bool fast_misaligned = (p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
+    // the wave-local kernel: tiles start on NCO rows when the chain shifts, on load vectors otherwise; irregular rows (take_fft) never run on it
+    if (p->spark) fast_misaligned = p->row_offsets_d != nullptr || ((first_window * p->W) % (p->has_shift ? (uint64_t)kSparkRow : (uint64_t)spl)) != 0;
     if (vec_ok && !fast_misaligned) {
         // windows [first_window, first_window + n_aligned): need-end rounded up to a vector fits in the slab
         const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
@@ -823,10 +864,11 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
         P.first_window = w_begin; P.n_windows = w_count;
         if (part == 1 && tail_tables) { P.rowtab = tabs->tail.d; P.rowtab_row0 = tabs->tail.row0; P.jtab = p->jtab256_d; }
         const uint64_t n_tiles = (w_count + P.G - 1) / P.G;
-        const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
+        uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
+        if (part == 0 && p->spark) { const uint64_t wgs = (n_tiles + 3) / 4; grid = (uint32_t)(wgs < cap ? wgs : cap); }      // a tile per WAVE, four waves per workgroup
         // dynamic tile queue for the main launch (static strided walk for the short unaligned tail and for tiny grids)
         P.work = nullptr;
-        if (part == 0 && (grid & 7u) == 0 && n_tiles >= 4ull * grid) { rc = ensure_work(tabs); if (rc) return rc; P.work = tabs->work; }
+        if (part == 0 && !p->spark && (grid & 7u) == 0 && n_tiles >= 4ull * grid) { rc = ensure_work(tabs); if (rc) return rc; P.work = tabs->work; }
         P.lds_dyn = (uint32_t)(part == 0 && p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes);
         if (part == 0 && p->jit_fn && !p->row_offsets_d) {
             void *args[] = {&P};
@@ -977,6 +1019,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // heuristics (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256; PAD = LDS pad elements per row)
     // [6] = tiles per FFT batch (FixedGeo::kBatch), [7] = workgroups per CU (0: as many as LDS / registers admit, at most 4)
     const bool lut8 = d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8;
+    // chains without a lowpass whose windows lie side by side: the wave-local kernel (k_spark), for every width it holds in a tile
+    p->spark = !p->has_fir && p->S == p->W && p->W <= kSparkMaxW && d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC;
     uint32_t tune[8] = {0, 0, 1, 8, 4, 1, 1, 0};
     uint32_t hint_flags = 0;
     bool tuned = false;
@@ -1162,6 +1206,11 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         pad = (uint32_t)p->fixed->pad;
         batch = (uint32_t)p->fixed->batch;
         kflags = (uint32_t)p->fixed->flags;
+    } else if (p->spark) {
+        p->spark_ts = spark_tile(p->W, p->nco);
+        G = p->spark_ts / p->W;                // windows per wave tile (the kernel derives the same number from its tile size)
+        p->nt = (int)(kSparkRow / spl_of(d.format));      // NCO rows of 512 samples: row table and lane table are laid out for that
+        kflags = kGeoSpark;
     } else {
         while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
         while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
@@ -1178,6 +1227,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->geo.G = G;
     p->kflags = kflags;
     p->launch_nt = p->nt + ((kflags & kGeoPipe3) ? ((kflags & kGeoWriteSink) ? 256 : 512) : ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0));
+    if (p->spark) p->launch_nt = kThreads;         // four waves per workgroup whatever the row geometry (p->nt = 512 / SPL only lays out the NCO tables)
     p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, (kflags & kGeoWriteSink) ? p->T : T_lds, &raw_elems, pad, batch, lut8, kflags, &p->geo.lds_main, spl_of(d.format), p->nt);     // the generic kernels (pad 1, batch 1) fit inside the same allocation
     if (kflags & kGeoWriteSink) {      // the streaming write kernel is laid out for T; the generic kernels' tile (an unaligned tail) for T + tile_extra
         uint32_t re_gen = 0;
@@ -1186,19 +1236,42 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         raw_elems = re_gen;
     }
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
+    if (p->spark) p->geo.lds_main = ((size_t)(p->W < 16 ? 16 : p->W) + 4 * (size_t)p->spark_ts) * 8;       // twiddles | four waves' transform buffers (k_spark)
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
 
-    p->fn = p->fixed ? p->fixed->fn : pick_generic(d.format, p->nco, p->has_fir, true);
+    p->fn = p->fixed ? p->fixed->fn : (p->spark ? pick_spark(d.format, p->nco, p->spark_ts) : pick_generic(d.format, p->nco, p->has_fir, true));
     p->fn_unaligned = pick_generic(d.format, p->nco, p->has_fir, false);
     if (!p->fn || !p->fn_unaligned) return fail(QD_ERR_UNSUPPORTED, "no kernel built for this format (QD_DEV_FAST build?)");
     {
         // plan-time specialisation for shapes without a built-in FixedGeo kernel
-        const bool want = !heavy && (tuned || (!p->fixed && jit_ok && (!write_sink || auto_variant)));
+        if (p->spark && jit_ok) {
+            // the same kernel with the width as a compile-time constant (butterfly loops unroll, one base butterfly instead of five,
+            // index arithmetic folds): cached builds always, a new one for streams of 1 GiB and more.  Falls back to the built-in
+            // runtime-width kernel — same tiling, same bytes.
+            JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, spark_lb(p->spark_ts, p->nco), kThreads,
+                     p->W, p->S, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull};
+            p->jit_fn = jit_chain_kernel(k, &p->jit_note, may_compile);
+        }
+        const bool want = !heavy && !p->spark && (tuned || (!p->fixed && jit_ok && (!write_sink || auto_variant)));
         if (want) {
             p->jit_fn = jit_chain_kernel(make_key(G, p->nt, jit_lb, jit_noslp, pad, batch, kflags), &p->jit_note, may_compile, &p->taps_h);
             if (tuned && !p->jit_fn) return fail(QD_ERR_UNSUPPORTED, "tile_hint build failed: %s", p->jit_note.c_str());
+            if (!p->jit_fn && auto_variant && fast_mode && fixed_exact) {
+                // QD_MODE_FAST had set the exact built-in kernel aside for a fused build that is not to be had: back to the built-in
+                // (exact) kernel with ITS tiling, not down to the generic kernels
+                p->fixed = fixed_exact;
+                G = p->fixed->G; p->nt = p->fixed->nt; pad = (uint32_t)p->fixed->pad; batch = (uint32_t)p->fixed->batch; kflags = (uint32_t)p->fixed->flags;
+                auto_variant = false;
+                uint32_t re2 = 0;
+                p->geo.G = G; p->kflags = kflags;
+                p->launch_nt = p->nt + ((kflags & kGeoPipe3) ? ((kflags & kGeoWriteSink) ? 256 : 512) : ((kflags & kGeoPipe) ? ((kflags & kGeoPipeFftWave) ? 128 : 64) : 0));
+                p->geo.lds_bytes = lds_for(G, p->W, p->S, p->D, T_lds, &re2, pad, batch, lut8, kflags, &p->geo.lds_main, spl_of(d.format), p->nt);
+                if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
+                p->geo.lds_raw_elems = re2;
+                p->fn = p->fixed->fn;
+            } else
             if (!p->jit_fn && auto_variant) {
                 // no variant build (not cached and too small a stream to compile for, or the build failed): the plain tiling —
                 // which the generic kernels run in as well
@@ -1232,6 +1305,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     int by_lds = (int)(kLdsMax / (p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes));
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
+    if (p->spark) { const int by_regs = spark_lb(p->spark_ts, p->nco); if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->launch_nt > kThreads) { int by_threads = 2048 / p->launch_nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
     if (tuned || heavy || auto_variant) { int by_regs = (jit_lb * 4 * 64) / p->launch_nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (tuned && tune[7] && (int)tune[7] < p->wg_per_cu) p->wg_per_cu = (int)tune[7];
@@ -1415,8 +1489,8 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->tile_windows = p->geo.G;
     info->threads = (uint32_t)p->launch_nt;
     info->lds_bytes = (uint32_t)(p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes);
-    info->kernel_kind = p->jit_fn ? 2u : (p->fixed ? 1u : 0u);
-    info->kernel_flags = (p->jit_fn || p->fixed) ? p->kflags : 0u;
+    info->kernel_kind = p->jit_fn ? 2u : ((p->fixed || p->spark) ? 1u : 0u);
+    info->kernel_flags = (p->jit_fn || p->fixed || p->spark) ? p->kflags : 0u;
     info->_reserved = 0;
     return QD_OK;
 }
@@ -1493,7 +1567,7 @@ int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint6
     uint64_t cw = target_bytes / (step * bps ? step * bps : 1);
     if (cw < p->geo.G) cw = p->geo.G;
     cw = (cw / p->geo.G) * p->geo.G;
-    if ((p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed)) {
+    if ((p->kflags & (kGeoFastP1 | kGeoPipe3 | kGeoSpark)) && (p->jit_fn || p->fixed || p->spark)) {
         // row-aligned kernels: a launch whose first window is off the row grid goes to the per-sample kernel (launch_chain), so
         // chunks start on windows that are multiples of lcm(G, ROW / gcd(ROW, S D))
         const uint64_t ROW = (uint64_t)p->nt * spl_of(p->d.format);
@@ -1757,7 +1831,8 @@ struct WsLease {                        // one workspace for the duration of a c
         }
         if (!ws) { ws = new Workspace(); ws->device = dev; }
         // hand-over between streams: the new stream waits (on the device) for the event behind the workspace's last call
-        if (ws->used && ws->last != st && ws->done && hipStreamWaitEvent(st, ws->done, 0) != hipSuccess) rc = fail(QD_ERR_HIP, "workspace hand-over: hipStreamWaitEvent failed");
+        // (always: `last` is kept to prefer a workspace this stream used, never to skip the wait — a handle may be a new stream at a recycled address)
+        if (ws->used && ws->done && hipStreamWaitEvent(st, ws->done, 0) != hipSuccess) rc = fail(QD_ERR_HIP, "workspace hand-over: hipStreamWaitEvent failed");
         if (!ws->done && hipEventCreateWithFlags(&ws->done, hipEventDisableTiming) != hipSuccess) { ws->done = nullptr; rc = fail(QD_ERR_HIP, "workspace: hipEventCreate failed"); }
         ws->last = st; ws->used = true;
     }
@@ -1806,6 +1881,7 @@ int cached_fft_plan(uint64_t W, uint64_t S, int kind, std::shared_ptr<CachedPlan
         p->geo.lds_main = p->geo.lds_bytes;
         p->geo.lds_raw_elems = raw_elems;
         p->fn = p->fn_unaligned;
+        p->spark = false; p->kflags = 0;           // irregular rows: the per-sample generic kernel only
     }
     if (g_plan_cache.size() >= kPlanCacheMax) g_plan_cache.erase(g_plan_cache.begin());     // the oldest entry; destroyed once unused
     g_plan_cache.push_back(std::make_shared<CachedPlan>(dev, W, S, kind, p));

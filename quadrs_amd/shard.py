@@ -47,6 +47,22 @@ def partition(n_windows, world, raw_step, raw_per_window, tile_windows=1):
     return shards
 
 
+def agree_tile_windows(tile_windows, dist, torch, device="cpu"):
+    """Every rank's shard table must come from ONE tiling.  A plan's tile_windows depends on which kernel the plan obtained (a
+    plan-time build that is cached on one rank and not on another, or fails on one, gives a different G), and ranks partitioning
+    with different tilings would disagree about window ranges and halo sizes — a hang or a gap.  Rank 0's value is broadcast;
+    a rank whose own plan tiles differently fails loudly unless rank 0's tiling is a multiple of its own (then its launches still
+    start on its tile grid).  `dist` None (one rank): the value itself."""
+    if dist is None:
+        return int(tile_windows)
+    t = torch.tensor([int(tile_windows)], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=0)
+    agreed = int(t.item())
+    if agreed % int(tile_windows) != 0:
+        raise RuntimeError(f"rank tiles by {tile_windows} windows, rank 0 by {agreed}: plans differ across ranks (plan-time kernel cache?)")
+    return agreed
+
+
 def alloc_slab(shard, bytes_per_sample, device, torch):
     """One buffer for everything `shard` reads: its own samples first, room for the halo behind them (filled by exchange)."""
     return torch.empty(shard.need_count * bytes_per_sample, dtype=torch.uint8, device=device)

@@ -195,6 +195,56 @@ def test_norm_special_values(engine, oracle):
     assert np.array_equal(np.isnan(ref), np.isnan(got)) and bits_equal(ref[~np.isnan(ref)], got[~np.isnan(got)])
 
 
+def _pythagorean_ties():
+    """(x, y) pairs whose hypot is EXACTLY half way between two f32 values: k * (a, b, c) with c k a 25-bit odd number and both
+    legs representable — the (float) of the f64 square root is then a tie (round-half-even), the case a short-form |X| must hand to
+    the IEEE path.  Scaled by a few powers of two; both orders, both signs."""
+    out = []
+    for a, b, c in ((3, 4, 5), (5, 12, 13), (8, 15, 17), (7, 24, 25), (20, 21, 29), (12, 35, 37), (9, 40, 41)):
+        lo, hi = (1 << 24) // c + 1, (1 << 25) // c
+        k = np.arange(lo | 1, hi, 2, dtype=np.int64)[::37]
+        ok = (a * k < (1 << 24)) | ((a * k) % 2 == 0)
+        ok &= (b * k < (1 << 24)) | ((b * k) % 2 == 0)
+        ok &= (b * k < (1 << 25)) & ((c * k) % 2 == 1)
+        k = k[ok]
+        for sc in (1.0, 2.0 ** -30, 2.0 ** 20):
+            xa, ya = (a * k).astype(np.float64) * sc, (b * k).astype(np.float64) * sc
+            out.append(np.stack([xa, ya], 1)); out.append(np.stack([-ya, xa], 1))
+    return np.concatenate(out).astype(np.float32)
+
+
+def test_norm_equals_hypotf(engine, oracle):
+    """|X| on the device (qd_device.h norm_ref: f32 reciprocal square root, one f64 Newton step, IEEE f64 sqrt only near an f32
+    rounding boundary) against glibc's hypotf, the function num-complex's norm() ends in (src/fft.rs:53): 2^28 random pairs over
+    +-40 binades with components of similar size (where sqrt's rounding matters), 2^26 with independent exponents over the whole
+    f32 range (subnormals, overflow), every Pythagorean tie, and the special values — bit for bit."""
+    rng = np.random.default_rng(20261005)
+
+    def check(x):
+        got = engine.fft_norm_batch(x, 1, x.shape[0], 1)[:, 0]
+        ref = oracle.norm(x)
+        nan = np.isnan(ref)
+        assert np.array_equal(nan, np.isnan(got))
+        bad = np.flatnonzero(ref.view(np.uint32)[~nan] != got.view(np.uint32)[~nan])
+        assert bad.size == 0, (bad.size, x[~nan][bad[:4]], ref[~nan][bad[:4]], got[~nan][bad[:4]])
+
+    n = 1 << 24
+    for _ in range(16):                                                     # 2^28 pairs
+        bits = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+        ex = (127 - 40 + rng.integers(0, 81, size=n, dtype=np.uint32))[:, None] + rng.integers(0, 5, size=(n, 2), dtype=np.uint32) - 2
+        x = ((bits & np.uint32(0x807FFFFF)) | (ex.astype(np.uint32) << np.uint32(23))).view(np.float32)
+        check(x)
+    for _ in range(4):                                                      # 2^26 pairs: any two finite floats, subnormals included
+        bits = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+        x = bits.view(np.float32)
+        x = x[np.isfinite(x).all(axis=1)]
+        check(np.ascontiguousarray(x))
+    check(_pythagorean_ties())
+    sp = np.array([0.0, -0.0, 1e-45, -1e-45, 1.1754944e-38, 1.0, 3.0, 4.0, 3.4028235e38, -3.4028235e38, 2.4e38, np.inf, -np.inf, np.nan,
+                   1.8446744e19, 5.421011e-20, 2.0 ** 48, 2.0 ** -48, 2.0 ** 47, 2.0 ** -49], dtype=np.float32)
+    check(np.stack(np.meshgrid(sp, sp), -1).reshape(-1, 2).copy())
+
+
 # ------------------------------------------------------------------ fused chain
 
 def test_cfg1_readme_known_answer_on_gpu(engine, oracle, cupboard):

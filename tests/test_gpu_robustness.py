@@ -720,3 +720,100 @@ def test_three_stage_kernel_with_the_tile_queue(engine):
         var.run_device(src, b)
         torch.cuda.synchronize()
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+# ------------------------------------------------------------------ chains without a lowpass: the wave-local kernel (k_spark)
+
+def _synth_bytes(fmt, n, seed):
+    rng = np.random.default_rng(seed)
+    if fmt == 0:
+        t = np.arange(n)
+        z = 0.3 * np.exp(2j * np.pi * (0.07 * t + 0.00002 * t * t)) + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        return np.stack([z.real, z.imag], 1).astype(np.float32).tobytes()
+    if fmt == 3:
+        return rng.integers(-32768, 32768, size=(n, 2), dtype=np.int64).astype(np.int16).tobytes()
+    return rng.integers(0, 256, size=(n, 2), dtype=np.int64).astype(np.uint8).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,shift", [(0, None), (0, 280000), (1, None), (1, 280000), (2, -1_234_567), (3, None), (3, 280000)])
+def test_wave_local_kernel_equals_generic_and_oracle(engine, oracle, fmt, shift):
+    """`from F [shift] sparkfft` with stride == width (README example 1's chain, src/fft.rs:28-65 straight over Shift / SampleFile) runs
+    on the wave-local kernel (kernel_flags bit 19).  Every width 1 ... 1024, all three epilogues, a stream that ends inside a tile
+    and inside a load vector, window sub-ranges that start on and off the NCO row grid, a slab that starts inside the stream: bit
+    for bit the generic kernel's output (QD_KERNEL_GENERIC), and the oracle's (bit-exact without a shift; the NCO's tolerance with)."""
+    import torch
+    from quadrs_amd import _ffi
+    bps = {0: 8, 1: 2, 2: 2, 3: 4}[fmt]
+    sr = 21_000_000
+    for W in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024):
+        n = 5 * 1024 + 3 * W + (7 if W > 4 else 1)
+        data = _synth_bytes(fmt, n, 1000 * fmt + W)
+        ch = oracle.Chain.from_bytes(data, fmt, sr)
+        if shift is not None:
+            ch = ch.shift(shift)
+        for epi, rng_ in ((engine.EPI_NORMS_F32, None), (engine.EPI_GLYPH_U8, (0.01, 0.5) if fmt == 0 else (0.3, 30.0)), (engine.EPI_BUCKET2_U8, None)):
+            if epi == engine.EPI_BUCKET2_U8 and W < 2:
+                continue
+            kw = dict(shift_hz=shift, width=W, stride=W, epilogue=epi, rng=rng_)
+            p = engine.Plan(fmt, sr, n, **kw)
+            g = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_GENERIC, **kw)
+            assert p.info.kernel_flags & 524288 and not (g.info.kernel_flags & 524288), (W, p.info.kernel_flags, g.info.kernel_flags)
+            assert p.n_windows == g.n_windows
+            a, b = p.run_host(data), g.run_host(data)
+            assert np.array_equal(a, b), (fmt, shift, W, epi, int((a != b).sum()))
+            if epi == engine.EPI_NORMS_F32:
+                ref, _ = ch.spark_fft(W, W)
+                assert ref.shape == a.shape
+                if shift is None:
+                    assert bits_equal(ref, a), (fmt, W)
+                else:
+                    mx = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-30)
+                    assert (np.abs(a.astype(np.float64) - ref) / np.spacing(mx.astype(np.float32))).max() <= 1.0, (fmt, W)
+                    assert (a.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.999
+                # window sub-ranges: on the row grid (512 samples), off it, and a device slab that starts inside the stream
+                nw = p.n_windows
+                for w0 in sorted({0, min(nw - 1, max(1, 512 // W)), min(nw - 1, max(1, 1024 // W) + 1), nw // 2}):
+                    cnt = nw - w0
+                    first, count = p.src_range(w0, cnt)
+                    sub = p.run_host(data[first * bps:(first + count) * bps], w0, cnt, src_first=first)
+                    assert np.array_equal(sub, a[w0:]), (fmt, shift, W, w0)
+                    src = torch.frombuffer(bytearray(data[first * bps:(first + count) * bps]), dtype=torch.uint8).cuda()
+                    out = torch.empty(cnt, W, dtype=torch.float32, device="cuda")
+                    p.run_device(src, out, w0, cnt, src_first=first, src_count=count)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(out.cpu().numpy(), a[w0:]), (fmt, shift, W, w0, "device")
+            p.close(); g.close()
+
+
+@pytest.mark.gpu
+def test_wave_local_kernel_many_tiles(engine, oracle):
+    """More tiles than resident waves (grid-stride walk, prefetch of the next tile, the last wave's short run): 2^24 cf32 samples,
+    W = 128 with and without a shift, against the generic kernel bit for bit and against the oracle on sampled windows."""
+    import torch
+    from quadrs_amd import _ffi
+    import bench
+    n = (1 << 24) + 5 * 128 + 3
+    dev = torch.device("cuda", 0)
+    slab = bench.synth_slab(torch, 0, 0, n, 0x5EED0002, dev)
+    host = slab.cpu().numpy().tobytes()
+    for shift in (None, 280000):
+        p = engine.Plan(0, 21_000_000, n, shift_hz=shift, width=128, stride=128)
+        g = engine.Plan(0, 21_000_000, n, shift_hz=shift, width=128, stride=128, kernel_policy=_ffi.KERNEL_GENERIC)
+        assert p.info.kernel_flags & 524288
+        a = torch.empty(p.n_windows, 128, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        p.run_device(slab, a); g.run_device(slab, b)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        ch = oracle.Chain.from_bytes(host, 0, 21_000_000)
+        if shift is not None:
+            ch = ch.shift(shift)
+        for w0 in (0, p.n_windows // 3, p.n_windows - 300):
+            ref, _ = ch.spark_fft(128, 128, first_window=w0, max_windows=300)
+            got = a[w0:w0 + 300].cpu().numpy()
+            if shift is None:
+                assert bits_equal(ref, got)
+            else:
+                assert (got.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.9999
+        p.close(); g.close()

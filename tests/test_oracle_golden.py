@@ -192,3 +192,42 @@ def test_panics_and_short_reads(oracle, cupboard):
     assert lp.len() == 1 + (1994 - 40) // 8
     assert lp.read_at(lp.len() - 1, 1)[0] == 0                         # len over-reports by one
     assert lp.read_at(lp.len(), 1)[0] == oracle.PANIC                  # valid < T underflow, src/filter.rs:76
+
+
+def test_device_norm_model_equals_hypotf(oracle):
+    """The device's short-form |X| (quadrs_amd/csrc/qd_device.h norm_ref), restated on the CPU in oracle/quadrs_oracle.c
+    (qo_device_norm_model), equals glibc hypotf — the function num-complex norm() ends in, src/fft.rs:53 — for 9e8 random pairs,
+    whatever value within +-2 ulp the hardware's reciprocal square root returns, and on every exact tie a Pythagorean triple makes.
+    The GPU itself is checked on 3e8 pairs by tests/test_gpu_parity.py::test_norm_equals_hypotf."""
+    import ctypes as C
+    L = oracle.lib()
+    total_slow = 0
+    for q_ulps in (-2, -1, 0, 1, 2):
+        for mode, spread, n in ((1, 40, 120_000_000), (1, 3, 40_000_000), (0, 126, 20_000_000)):
+            ns = C.c_uint64(0)
+            bad = L.qo_device_norm_selftest(n, 0x5EED + 17 * q_ulps + mode, spread, mode, q_ulps, C.byref(ns))
+            assert bad == 0, (q_ulps, mode, spread, bad)
+            if mode == 1:
+                assert ns.value < n // 10_000          # the IEEE path is the rare one (3e-5 of random inputs)
+                total_slow += ns.value
+    assert total_slow > 1000                           # ... and it IS exercised
+    # exact ties: hypot = k * c with k c a 25-bit odd number; the model must hand them to the IEEE path and agree with hypotf
+    import math
+    n_tie = 0
+    for a, b, c in ((3, 4, 5), (5, 12, 13), (8, 15, 17), (7, 24, 25), (20, 21, 29)):
+        lo, hi = (1 << 24) // c + 1, (1 << 25) // c
+        for k in range(lo | 1, hi, 2 * 257):
+            if (a * k >= (1 << 24) and (a * k) % 2) or (b * k >= (1 << 24) and (b * k) % 2) or b * k >= (1 << 25):
+                continue
+            for sc in (1.0, 2.0 ** -30, 2.0 ** 20):
+                x, y = np.float32(a * k * sc), np.float32(-b * k * sc)
+                sl = C.c_int(0)
+                for q_ulps in (-1, 0, 1):
+                    got = np.float32(L.qo_device_norm_model(x, y, q_ulps, C.byref(sl)))
+                    assert sl.value == 1 and got == np.float32(math.hypot(float(x), float(y))) and got == oracle.norm(np.array([[x, y]], np.float32))[0]
+                n_tie += 1
+    assert n_tie > 5000
+    for x, y in ((0.0, 0.0), (-0.0, 0.0), (1e-45, 0.0), (3e38, 3e38), (np.inf, np.nan), (np.nan, 1.0), (1.0, np.nan), (2.0 ** 48, 1.0), (2.0 ** -49, 2.0 ** -49)):
+        got = np.float32(L.qo_device_norm_model(np.float32(x), np.float32(y), 0, None))
+        ref = oracle.norm(np.array([[x, y]], np.float32))[0]
+        assert (np.isnan(got) and np.isnan(ref)) or got.view(np.uint32) == ref.view(np.uint32), (x, y, got, ref)

@@ -85,13 +85,20 @@ def _hip_worker(rank, world, port, n, cfg, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     shift, (fc, D, T), W, S = cfg
     rng = np.random.default_rng(4321)
     x = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)       # every rank can rebuild the stream
     plan = Q.Plan(0, 21_000_000, n, shift_hz=shift, lowpass=(fc, D, T), width=W, stride=S)
+    if rank == world:
+        # the extra process: the single-rank reference run of the whole stream, also a child — the pytest process itself never
+        # initialises HIP in this test, so the next parametrised case still forks its ranks from a GPU-free parent
+        np.save(os.path.join(out_dir, "hip_whole.npy"), plan.run_host(x.tobytes()))
+        plan.close()
+        return
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     info = plan.info
-    shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, info.tile_windows)
+    tile = SH.agree_tile_windows(int(info.tile_windows), dist, torch)       # one tiling for every rank's shard table (rank 0's; differing plans fail here)
+    shards = SH.partition(plan.n_windows, world, info.raw_step, info.raw_per_window, tile)
     me = shards[rank]
     host = SH.alloc_slab(me, 8, "cpu", torch)
     host[:me.own_count * 8] = torch.from_numpy(x[me.own_first:me.own_first + me.own_count].copy()).view(torch.uint8).reshape(-1)
@@ -118,18 +125,14 @@ def _hip_worker(rank, world, port, n, cfg, out_dir):
 ])
 def test_sharded_hip_ranks_equal_single_rank(tmp_path, world, cfg, n):
     """The multi-rank path with the HIP kernels: `world` rank processes (gloo, all on cuda:0) each run their window range from
-    their own slab + exchanged halo; the concatenation must equal the single-rank HIP run bit for bit.  Scheduled before any
-    test that initialises the GPU in this process (conftest.py: spawns_gpu_ranks)."""
+    their own slab + exchanged halo; the concatenation must equal the single-rank HIP run (made by one more child process) bit for
+    bit.  Scheduled before any test that initialises the GPU in this process (conftest.py: spawns_gpu_ranks), and the test itself
+    makes no HIP call in the pytest process, so every parametrised case starts its ranks from a GPU-free parent."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_hip_worker, args=(world, port, n, cfg, str(tmp_path)), nprocs=world, join=True)
-    sys.path.insert(0, ROOT)
-    import quadrs_amd as Q
-    shift, (fc, D, T), W, S = cfg
-    rng = np.random.default_rng(4321)
-    x = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)
-    plan = Q.Plan(0, 21_000_000, n, shift_hz=shift, lowpass=(fc, D, T), width=W, stride=S)
-    whole = plan.run_host(x.tobytes())
+    # `world` ranks + one process for the single-rank reference run: the parent only compares files (no HIP call in this process)
+    mp.spawn(_hip_worker, args=(world, port, n, cfg, str(tmp_path)), nprocs=world + 1, join=True)
+    whole = np.load(os.path.join(str(tmp_path), "hip_whole.npy"))
     parts = np.concatenate([np.load(os.path.join(str(tmp_path), f"hip_rank{r}.npy")) for r in range(world)])
     assert parts.shape == whole.shape
     assert np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
