@@ -1233,6 +1233,30 @@ __device__ __forceinline__ float2 fir_prefix(const float2 *raw, uint32_t t0, uin
 // One wave transforms a parked tile (pg windows at fbp, FIR output in rustfft's digit-reversed order) and writes its output:
 // LDS operations of one wave execute in order, so the passes are separated by a compiler-level fence only.  twl = the layer
 // twiddles (LDS or global), pw0 = the tile's first window.
+// freq_levels on transformed windows parked in LDS (one wave): the norms replace the samples in place (every lane reads its share
+// first), then one lane per window forms the two sequential half sums (src/fft.rs:95-97).  K: bins per lane the buffer may hold.
+template <class GeoT, uint32_t K>
+__device__ __forceinline__ void wave_bucket_epilogue_fn(const ChainParams &P, const GeoT &geo, float2 *fbp, uint64_t pw0, uint32_t pg, uint32_t lane) {
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    const uint64_t wrel = pw0 - P.out_window0;
+    const uint32_t n_out_s = pg << geo.logW;
+    float nm[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; nm[k] = o < n_out_s ? norm_ref(fbp[o]) : 0.f; }
+    wsync();
+    float *nb = reinterpret_cast<float *>(fbp);
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; if (o < n_out_s) nb[o] = nm[k]; }
+    wsync();
+    for (uint32_t wl = lane; wl < pg; wl += 64) {                           // (more than 64 windows per buffer: the wave-local kernel at W < 16)
+        const float *q = nb + (wl << geo.logW);
+        float first = 0.f, second = 0.f;
+        for (uint32_t k = 0; k < geo.W / 2; ++k) first = first + q[k];
+        for (uint32_t k = geo.W / 2; k < geo.W; ++k) second = second + q[k];
+        reinterpret_cast<uint8_t *>(P.out)[wrel + wl] = first < second ? 0 : 1;
+    }
+}
+
 template <class GeoT, uint32_t KB = 0 /* bucket epilogue: bins per lane the caller's buffer may hold (0: from the geometry) */>
 __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const GeoT &geo, const float2 *twl, float2 *fbp, uint64_t pw0, uint32_t pg, uint32_t tid) {
     uint32_t lane = tid & 63u;
@@ -1289,24 +1313,8 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
     const uint64_t wrel = pw0 - P.out_window0;
     const uint32_t n_out_s = pg << geo.logW;
     if (P.epi == 2) {
-        // freq_levels: the norms replace the transformed samples in place (every lane reads its share first), then one lane
-        // per window forms the two sequential half sums (src/fft.rs:95-97)
         constexpr uint32_t K = KB ? KB : (GeoT::kFixed ? (GeoT::G_ct * GeoT::W_ct + 63) / 64 : 1);
-        float nm[K];
-#pragma unroll
-        for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; nm[k] = o < n_out_s ? norm_ref(fbp[o]) : 0.f; }
-        wsync();
-        float *nb = reinterpret_cast<float *>(fbp);
-#pragma unroll
-        for (uint32_t k = 0; k < K; ++k) { const uint32_t o = lane + 64 * k; if (o < n_out_s) nb[o] = nm[k]; }
-        wsync();
-        for (uint32_t wl = lane; wl < pg; wl += 64) {                       // (more than 64 windows per buffer: the wave-local kernel at W < 16)
-            const float *q = nb + (wl << geo.logW);
-            float first = 0.f, second = 0.f;
-            for (uint32_t k = 0; k < geo.W / 2; ++k) first = first + q[k];
-            for (uint32_t k = geo.W / 2; k < geo.W; ++k) second = second + q[k];
-            reinterpret_cast<uint8_t *>(P.out)[wrel + wl] = first < second ? 0 : 1;
-        }
+        wave_bucket_epilogue_fn<GeoT, K>(P, geo, fbp, pw0, pg, lane);
     } else {
         float *outf = reinterpret_cast<float *>(P.out) + (wrel << geo.logW);
         uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << geo.logW);
@@ -3024,6 +3032,27 @@ constexpr uint32_t kGeoSpark = 524288;       // FLAGS bit 19 (reported in qd_pla
 constexpr uint32_t kSparkRow = 512;          // samples per NCO row of this kernel, every format
 constexpr uint32_t kSparkMaxW = 1024;
 
+// Which tiles a wave takes.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with an L2 of its own whose
+// channels interleave the address space in 4 KiB steps.  A chip-wide grid-stride walk hands XCD x the 32 KiB chunks x, x + 8, x + 16 ...
+// of the stream — a quarter-MiB stride under which an XCD only ever touches HALF of its L2 channels (16 GiB cf32, W = 128: 3.0 TB/s
+// of reads with every arithmetic phase ablated, profiles/r04/spark_ablate.log).  So each XCD walks one contiguous eighth of the tile
+// range and its waves sit on neighbouring tiles: a few MiB of contiguous addresses in flight per XCD, every channel busy.
+struct SparkWalk {
+    uint64_t first, stride, end;
+    __device__ __forceinline__ SparkWalk(uint64_t n_tiles, uint32_t wave) {
+        constexpr uint32_t WPG = kThreads / 64;
+        if ((gridDim.x & 7u) == 0 && n_tiles >= 64) {
+            const uint64_t n8 = (n_tiles + 7) / 8, lo = (uint64_t)(blockIdx.x & 7u) * n8;
+            first = lo + (uint64_t)(blockIdx.x >> 3) * WPG + wave;
+            stride = (uint64_t)(gridDim.x >> 3) * WPG;
+            end = lo + n8 < n_tiles ? lo + n8 : n_tiles;
+            if (lo >= n_tiles) { first = n_tiles; end = n_tiles; }
+        } else {
+            first = (uint64_t)blockIdx.x * WPG + wave; stride = (uint64_t)gridDim.x * WPG; end = n_tiles;
+        }
+    }
+};
+
 template <int FMT> struct SparkTraits {
     using FT = FmtTraits<FMT>;
     static constexpr uint32_t SPL = FT::SPL, CH = 64u * SPL, RQ = kSparkRow / CH;       // chunk: one wave-wide load; RQ chunks per NCO row
@@ -3081,9 +3110,10 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
     }
 
     const uint64_t n_tiles = (P.n_windows + G - 1) / G;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (kThreads / 64);
-    uint64_t tile = (uint64_t)blockIdx.x * (kThreads / 64) + wave;
-    if (tile >= n_tiles) return;                                           // (after the barrier; wave-uniform)
+    SparkWalk walk(n_tiles, wave);
+    uint64_t tile = walk.first;
+    const uint64_t n_waves = walk.stride, tile_end = walk.end;
+    if (tile >= tile_end) return;                                          // (after the barrier; wave-uniform)
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     auto rsrc_of = [&](uint64_t t) {
@@ -3111,7 +3141,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
     auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     while (true) {
         const uint64_t tile_n = tile + n_waves;
-        const auto rsrc_n = rsrc_of(tile_n < n_tiles ? tile_n : tile);      // last tile of this wave: harmless re-loads
+        const auto rsrc_n = rsrc_of(tile_n < tile_end ? tile_n : tile);     // last tile of this wave: harmless re-loads
         const uint64_t w0 = P.first_window + tile * G, left_w = P.first_window + P.n_windows - w0;
         const uint32_t g_cnt = left_w < G ? (uint32_t)left_w : G;
         const_f64_p rows = nullptr;
@@ -3163,7 +3193,236 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
         wsync();
         wave_fft_epilogue_fn<GeoT, TS / 64>(P, geo, twl, fbw, w0, g_cnt, tid);
         wsync();                                                            // the next tile's samples overwrite what the epilogue read
-        if (tile_n >= n_tiles) break;
+        if (tile_n >= tile_end) break;
+        tile = tile_n;
+    }
+}
+
+
+// ---------------------------------------------------------------- k_spark2: the same chain with the first FFT pass out of REGISTERS (FLAGS bits 19 + 20)
+//
+// k_spark parks every sample in LDS, then reads the base butterflies' inputs back: 16 points per lane written with a lane stride that
+// conflicts 2-way, read with one that conflicts 4- to 8-way, for the one pass of the transform whose inputs are nothing but the loaded
+// samples in another order.  rustfft's Radix4 starts from the transposed input (bitreversed_transpose: position y + rev4(x) * base
+// holds input x + y * width, width = W / base = 4^layers): base butterfly `x` works on inputs x, x + width, x + 2 width, ... — a COLUMN
+// of the window seen as a base x width matrix.  So here a lane loads a column pair directly: lane (g, xp) of a wave issues `base` row
+// loads of 16 bytes, row y at byte (g W + y width + 2 xp) * 8 of the tile; the lanes of one window cover width * 8 contiguous bytes per
+// instruction (128 B for W = 128, 512 B for W = 512 / 1024 — whole cache lines, each fetched by exactly one instruction).  The two
+// base butterflies of the lane run on those registers, their outputs go to LDS once, the radix-4 layers run in place (every lane's
+// butterflies unrolled: their reads are issued together), and the LAST layer never stores: a butterfly's four results are bins
+// i, i + W/4, i + W/2, i + 3W/4, i.e. after the fftshift four outputs of the same window, so |X| (and the glyph) go from registers to
+// HBM.  The registers the rows arrived in are refilled with the NEXT tile's rows as soon as the base pass has consumed them — that
+// is the prefetch, with no registers of its own.  Layer twiddles: a lane's butterflies t = lane + 64 k share i = t mod cols while
+// cols <= 64, so those twiddles live in registers; wider layers read them from LDS.
+// With a shift: the lane's samples sit at 2 base different places j of their NCO row (rows of 512 samples), so the lane constants
+// (cos, sin)(j ratio) come from an LDS copy of the lane table (one ds_read_b128 per sample) instead of 64 registers, the row base is
+// selected per lane from the tile's rows; same table entries, same operations as k_chain: bit-identical output.
+// cf32, W = 128 ... 1024 (width 16 or 64); everything else stays on k_spark.  Tile: 64 lanes x 2 columns x base rows = 1024 samples
+// (base 8: W = 128, 512) or 2048 (base 16: W = 256, 1024).
+constexpr uint32_t kGeoSparkReg = 1048576;   // FLAGS bit 20
+
+template <class GeoT> struct Spark2 {
+    static constexpr uint32_t W = GeoT::W, base = GeoT::base_len, layers = GeoT::layers, width = W / base;
+    static constexpr uint32_t LPW = width / 2, GW = 64 / (LPW ? LPW : 1), TS = GW * W, NBF = TS / 256;   // lanes per window, windows per tile, butterflies per lane and layer
+    static constexpr bool ok = GeoT::kFixed && (base == 8 || base == 16) && layers >= 1 && (width == 16 || width == 64) && GeoT::S == W && GeoT::D == 1 && GeoT::T == 0;
+    static constexpr uint32_t kRows = TS / kSparkRow;                  // NCO rows per tile (2 or 4)
+    static constexpr uint32_t lds_bytes(bool shift) { return ((W < 16u ? 16u : W) + 4u * TS) * 8u + (shift ? kSparkRow * 16u : 0u); }
+};
+
+template <int NCO, class GeoT, int LB, int EPI /* the plan's qd_epilogue, compile-time: the tile loop carries no sink dispatch */>
+__global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
+    using K = Spark2<GeoT>;
+    static_assert(K::ok, "k_spark2: cf32, stride == width, W = base * 16 or base * 64");
+    constexpr bool HAS_SHIFT = NCO != 0;
+    constexpr uint32_t W = K::W, logW = GeoT::logW, base = K::base, layers = K::layers, width = K::width, LPW = K::LPW, GW = K::GW, TS = K::TS, NBF = K::NBF;
+    const GeoT geo(P);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *twl = reinterpret_cast<float2 *>(smem);                        // layer twiddles (W - base entries)
+    double2 *jt = reinterpret_cast<double2 *>(twl + W);                    // NCO lane table (512 entries), chains with a shift only
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *fbw = twl + W + (HAS_SHIFT ? 2u * kSparkRow : 0u) + (size_t)wave * TS;
+    for (uint32_t i = tid; i < W - base; i += kThreads) twl[i] = P.tw[i];
+    if constexpr (HAS_SHIFT) { for (uint32_t i = tid; i < kSparkRow; i += kThreads) jt[i] = P.jtab[i]; }
+    __syncthreads();                                                       // the only workgroup barrier
+
+    const uint32_t g = lane / LPW, xp = lane % LPW;                        // this lane's window of the tile and its column pair (2 xp, 2 xp + 1)
+    // LDS positions of the lane's two base butterflies' outputs (contiguous runs of `base` points)
+    const uint32_t p0 = g * W + (rev4(2 * xp, layers) << GeoT::log_base), p1 = g * W + (rev4(2 * xp + 1, layers) << GeoT::log_base);
+    const uint64_t n_tiles = (P.n_windows + GW - 1) / GW;
+    SparkWalk walk(n_tiles, wave);
+    uint64_t tile = walk.first;
+    const uint64_t n_waves = walk.stride, tile_end = walk.end;
+    if (tile >= tile_end) return;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    auto rsrc_of = [&](uint64_t t) {
+        const uint64_t ns = (P.first_window + t * GW) << logW, end = P.src_first + P.src_count;
+        const uint64_t left = ns < end ? (end - ns) * 8 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * 8, 0,
+                                                 left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
+    };
+    const uint32_t voff = (g * W + 2 * xp) * 8;                             // lane's byte offset inside a row of its window
+    v4u_t raw[base];
+    auto load_rows = [&](const decltype(rsrc_of(0)) &rsrc) {
+#pragma unroll
+        for (uint32_t y = 0; y < base; ++y) raw[y] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(y * width * 8), 2 /* nt */);
+    };
+    load_rows(rsrc_of(tile));
+    if constexpr (EPI != 2) {
+        // vmcnt retires in order and counts stores too.  Inside the loop the next tile's row loads are followed by this tile's 4 NBF
+        // output stores before the rows are used at the top of the next iteration, so the wait there is vmcnt(4 NBF + base - 1 - y)
+        // — but only if the loop's entry edge carries the same queue as its back edge: the waitcnt pass merges the two and, entering
+        // with the loads alone, falls back to vmcnt(0), i.e. every tile waits for its own stores to land.  So the entry edge issues
+        // the same number of stores through an EMPTY descriptor: the range check drops them, the counter sees them.
+        const auto none = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out), 0, 0, 0x00020000);
+#pragma unroll
+        for (uint32_t q = 0; q < 4 * NBF; ++q) {
+            if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(0u, none, (int)(lane * 4 + q * 256), 0, 2);       // (distinct addresses: identical stores would be merged)
+            else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, none, (int)(lane + q * 64), 0, 2);
+        }
+    }
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    while (true) {
+        const uint64_t tile_n = tile + n_waves;
+        const uint64_t w0 = P.first_window + tile * GW, left_w = P.first_window + P.n_windows - w0;
+        const uint32_t g_cnt = left_w < GW ? (uint32_t)left_w : GW;
+        constexpr uint32_t OBW = EPI == 0 ? 4u * W : W;                     // output bytes per window (norms f32 / glyph u8)
+        const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * OBW, 0, g_cnt * OBW, 0x00020000);
+        // ---- NCO row bases of this lane: the tile's rows are wave-uniform (scalar loads), a lane needs the one(s) its window lies in
+        RowBase rbl[W > kSparkRow ? W / kSparkRow : 1];
+        if constexpr (HAS_SHIFT) {
+            const_f64_p rows = (const_f64_p)(uintptr_t)(P.rowtab + (((w0 << logW) / kSparkRow) - P.rowtab_row0));
+            constexpr uint32_t RPW = W > kSparkRow ? W / kSparkRow : 1;    // rows per window
+#pragma unroll
+            for (uint32_t h = 0; h < RPW; ++h) {
+                // lane's row index inside the tile: windows of W >= 512 span RPW rows each, smaller ones share a row
+                const uint32_t ridx = W >= kSparkRow ? g * RPW + h : (g * W) / kSparkRow;
+                RowBase sel = load_rowbase_at(rows, 0);
+#pragma unroll
+                for (uint32_t r = 1; r < K::kRows; ++r) {
+                    const RowBase cand = load_rowbase_at(rows, r);
+                    if (ridx == r) sel = cand;
+                }
+                rbl[h] = sel;
+            }
+        }
+        // ---- pass 1: the base butterflies of the lane's two columns, out of the row registers
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float2 v[base];
+#pragma unroll
+            for (uint32_t y = 0; y < base; ++y) {
+                float2 x = u == 0 ? make_float2(__uint_as_float(raw[y].x), __uint_as_float(raw[y].y)) : make_float2(__uint_as_float(raw[y].z), __uint_as_float(raw[y].w));
+                if constexpr (HAS_SHIFT) {
+                    const uint32_t jrow = (W >= kSparkRow ? 0u : (g * W) % kSparkRow) + (y * width) % kSparkRow;      // sample's place in its NCO row (before the column)
+                    const uint32_t j = jrow + 2 * xp + (uint32_t)u;
+                    const double2 cs = jt[j];
+                    LaneRot lr; lr.jf = (double)j; lr.c = cs.x; lr.s = cs.y;
+                    const RowBase &rb = rbl[W > kSparkRow ? (y * width) / kSparkRow : 0];
+                    x = cmul_pk(x, nco_mul<NCO == 2>(rb, lr, P.ratio));     // buf[i] *= mul (src/shift.rs:51)
+                }
+                v[y] = x;
+            }
+#if !(defined(QD_SPARK_ABL) && (QD_SPARK_ABL & 8))
+            if constexpr (base == 16) bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2); else bf8(v, P.root2);
+#endif
+            float2 *d = fbw + (u == 0 ? p0 : p1);
+#pragma unroll
+            for (uint32_t y = 0; y < base; ++y) d[y] = v[y];
+            __builtin_amdgcn_sched_barrier(0);                              // one column at a time (registers)
+        }
+        __builtin_amdgcn_sched_barrier(0);                                  // the rows are consumed: their registers take the next tile's rows
+        load_rows(rsrc_of(tile_n < tile_end ? tile_n : tile));              // (last tile of this wave: harmless re-loads)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- radix-4 layers in place; the last one feeds the epilogue from registers
+        uint32_t cols = base, log_cols = GeoT::log_base, tw_off = 0;
+        uint32_t lo = lane;
+        asm volatile("" : "+v"(lo));            // opaque per tile: the butterflies' LDS / output addresses are rebuilt, not hoisted out of the tile loop and spilled
+#pragma unroll
+        for (uint32_t l = 0; l < layers; ++l) {
+            wsync();
+#if defined(QD_SPARK_ABL) && (QD_SPARK_ABL & 4)
+            if (l + 1 < layers) { tw_off += 3 * cols; cols *= 4; log_cols += 2; continue; }       // timing-only ablation: the last layer alone
+#endif
+            const bool last = l + 1 == layers;
+            // layers of at most 64 columns: a lane's butterflies t = lane + 64 k share i = t mod cols, hence their three twiddles — read
+            // once per tile and layer (cheaper than six registers per layer held across the whole tile loop, which spill)
+            float2 tc1 = make_float2(0.f, 0.f), tc2 = tc1, tc3 = tc1;
+            if (cols <= 64) { const uint32_t i = lo & (cols - 1); tc1 = twl[tw_off + 3 * i]; tc2 = twl[tw_off + 3 * i + 1]; tc3 = twl[tw_off + 3 * i + 2]; }
+            // the lane's NBF butterflies two at a time: eight reads in flight, then the arithmetic; the scheduling barriers keep the
+            // pairs (and, in the last layer, the four |X| of a butterfly) from being interleaved into one register-hungry block
+            constexpr uint32_t KB = 2;
+#pragma unroll
+            for (uint32_t k0 = 0; k0 < NBF; k0 += KB) {
+                float2 s[KB][4];
+                float2 *dp[KB];
+#pragma unroll
+                for (uint32_t kk = 0; kk < KB; ++kk) {
+                    const uint32_t t = lo + 64 * (k0 + kk), chunk = t >> log_cols, i = t & (cols - 1);
+                    dp[kk] = fbw + (size_t)chunk * 4 * cols + i;
+                    s[kk][0] = dp[kk][0]; s[kk][1] = dp[kk][cols]; s[kk][2] = dp[kk][2 * cols]; s[kk][3] = dp[kk][3 * cols];
+                }
+#pragma unroll
+                for (uint32_t kk = 0; kk < KB; ++kk) {
+                    float2 t1, t2, t3;
+                    if (cols <= 64) { t1 = tc1; t2 = tc2; t3 = tc3; }
+                    else { const uint32_t i = (lo + 64 * (k0 + kk)) & (cols - 1); t1 = twl[tw_off + 3 * i]; t2 = twl[tw_off + 3 * i + 1]; t3 = twl[tw_off + 3 * i + 2]; }
+                    s[kk][1] = cmul(s[kk][1], t1); s[kk][2] = cmul(s[kk][2], t2); s[kk][3] = cmul(s[kk][3], t3);
+                    bf4(s[kk][0], s[kk][1], s[kk][2], s[kk][3]);
+                }
+                if (!last || EPI == 2) {
+#pragma unroll
+                    for (uint32_t kk = 0; kk < KB; ++kk) { dp[kk][0] = s[kk][0]; dp[kk][cols] = s[kk][1]; dp[kk][2 * cols] = s[kk][2]; dp[kk][3 * cols] = s[kk][3]; }
+                } else {
+                    // cols == W / 4: butterfly t of the tile is butterfly i of window t >> log_cols; result k is bin i + k W/4, output (bin + W/2) mod W.
+                    // The four |X| of a butterfly take the short form together and test ONE flag for the IEEE form (3e-5 of the bins).
+#pragma unroll
+                    for (uint32_t kk = 0; kk < KB; ++kk) {
+                        const uint32_t t = lo + 64 * (k0 + kk), gw = t >> log_cols, i = t & (cols - 1);
+                        float nm[4];
+                        bool sl[4];
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q) {                  // output q * W/4 + i is bin ((q + 2) & 3) * W/4 + i
+                            const float2 xv = s[kk][(q + 2) & 3];
+#if defined(QD_SPARK_ABL) && (QD_SPARK_ABL & 2)
+                            nm[q] = xv.x; sl[q] = false;                    // timing-only ablation: no |X|
+#else
+                            nm[q] = norm_fast(xv.x, xv.y, sl[q]);
+#endif
+                        }
+                        if (__builtin_expect(sl[0] | sl[1] | sl[2] | sl[3], 0)) {
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; ++q) if (sl[q]) nm[q] = norm_ieee(s[kk][(q + 2) & 3].x, s[kk][(q + 2) & 3].y);
+                        }
+#if defined(QD_SPARK_ABL) && (QD_SPARK_ABL & 1)
+                        if (nm[0] + nm[1] + nm[2] + nm[3] != 12345.678f) continue;     // timing-only ablation: no output stores
+#endif
+                        // Stores through a per-tile buffer descriptor that ends with the tile's last VALID window: a store past it (the
+                        // short last tile of a launch) is dropped by the range check, so the tile loop has no store branch, every tile
+                        // issues the same number of vector-memory operations and the waits for the prefetched rows stay COUNTED
+                        // (vmcnt retires in order: a conditional store between the row loads and their use forces vmcnt(0), i.e. a
+                        // wait for the tile's own stores to land).  Non-temporal: the output is written once and not read here.
+                        const uint32_t ob = (gw << logW) + i;               // element offset inside the tile's output
+                        if constexpr (EPI == 0) {
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)((ob + q * cols) * 4), 0, 2);
+                        } else {
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep), orsrc, (int)(ob + q * cols), 0, 2);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tw_off += 3 * cols; cols *= 4; log_cols += 2;
+        }
+        if constexpr (EPI == 2) {                                           // freq_levels: |X| through LDS, one lane per window sums the halves in order (src/fft.rs:95-97)
+            wsync();
+            wave_bucket_epilogue_fn<GeoT, TS / 64>(P, geo, fbw, w0, g_cnt, lane);
+        }
+        wsync();                                                            // the next tile's base outputs overwrite what this tile's layers read
+        if (tile_n >= tile_end) break;
         tile = tile_n;
     }
 }

@@ -49,12 +49,13 @@ __device__ __forceinline__ float2 rot90(float2 v) { return make_float2(v.y, -v.x
 // num-complex norm() = re.hypot(im) -> glibc 2.35 __hypotf, which is
 // (float)sqrt((double)x*x + (double)y*y) with inf/nan screened first (checked bit-for-bit
 // against glibc on 2e8 random pairs).  reference: src/fft.rs:53,95-96.
-__device__ __forceinline__ float norm_ieee(float x, float y, double s) {      // the literal form: IEEE f64 sqrt, ~20 f64-rate instructions
+__device__ __forceinline__ float norm_ieee(float x, float y) {      // the literal form: IEEE f64 sqrt, ~20 f64-rate instructions
     if (!(__builtin_isfinite(x) && __builtin_isfinite(y))) {
         if (__builtin_isinf(x) || __builtin_isinf(y)) return __builtin_inff();
         return x + y;
     }
-    return (float)__builtin_sqrt(s);
+    const double dx = (double)x, dy = (double)y;
+    return (float)__builtin_sqrt(__builtin_fma(dx, dx, dy * dy));
 }
 // Round 4: the same VALUE in ~40 % fewer issue slots.  s = x^2 + y^2 in f64 as glibc forms it (the products are exact, one
 // rounding); then r = sf * rsq(sf), sf = (float)s (v_rsq_f32: 1 ulp, so r has ~22 good bits) and ONE Newton step in f64,
@@ -68,8 +69,8 @@ __device__ __forceinline__ float norm_ieee(float x, float y, double s) {      //
 // The test tree restates this on the CPU (with the reciprocal perturbed by +-2 ulp) against glibc's hypotf on 10^9 pairs and
 // every tie a Pythagorean triple can make (tests/test_oracle_golden.py::test_device_norm_model_equals_hypotf); on the device
 // tests/test_gpu_parity.py::test_norm_equals_hypotf runs 2.7e8 pairs + the structured cases through the kernels.
-__device__ __forceinline__ float norm_ref(float2 v) {
-    const float x = v.x, y = v.y;
+// norm_fast: the short form alone; `slow` says the IEEE form must decide (callers with several values to take test ONE flag).
+__device__ __forceinline__ float norm_fast(float x, float y, bool &slow) {
     const double dx = (double)x, dy = (double)y;
     const double s = __builtin_fma(dx, dx, dy * dy);      // both squares are exact in f64: the same single rounding as dx*dx + dy*dy
     const uint32_t hi = (uint32_t)(__builtin_bit_cast(uint64_t, s) >> 32);
@@ -80,9 +81,14 @@ __device__ __forceinline__ float norm_ref(float2 v) {
     const double e = __builtin_fma(-rd, rd, s);
     const double g = __builtin_fma(e, (double)qh, rd);
     const uint32_t m = ((uint32_t)__builtin_bit_cast(uint64_t, g) & 0x1fffffffu) - (0x10000000u - 4096u);
-    const bool fast = (hi - ((1023u - 96u) << 20)) < (192u << 20) && m >= 8192u;
-    if (__builtin_expect(fast, 1)) return (float)g;
-    return norm_ieee(x, y, s);
+    slow = !((hi - ((1023u - 96u) << 20)) < (192u << 20) && m >= 8192u);
+    return (float)g;
+}
+__device__ __forceinline__ float norm_ref(float2 v) {
+    bool slow;
+    const float r = norm_fast(v.x, v.y, slow);
+    if (__builtin_expect(slow, 0)) return norm_ieee(v.x, v.y);
+    return r;
 }
 
 // ---------------------------------------------------------------- unpack (src/lib.rs:241-255)

@@ -395,9 +395,10 @@ const FixedEntry *find_fixed(int fmt, int nco, uint32_t W, uint32_t S, uint32_t 
 struct JitKey {
     int fmt, nco, fir, rch, whole, lb, nt; uint32_t W, S, D, T, G; uint32_t firb = 8, firr = 1; int noslp = 0; uint32_t pad = 1, batch = 1, flags = 0;
     uint64_t taps_hash = 0;        // baked-taps builds: FNV-1a of the filter (the code depends on it)
+    int epi = 0;                   // kernels that take the sink as a template argument (k_spark2)
     bool operator<(const JitKey &o) const {
-        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr, noslp, pad, batch, flags, taps_hash) <
-               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr, o.noslp, o.pad, o.batch, o.flags, o.taps_hash);
+        return std::tie(fmt, nco, fir, rch, whole, lb, nt, W, S, D, T, G, firb, firr, noslp, pad, batch, flags, taps_hash, epi) <
+               std::tie(o.fmt, o.nco, o.fir, o.rch, o.whole, o.lb, o.nt, o.W, o.S, o.D, o.T, o.G, o.firb, o.firr, o.noslp, o.pad, o.batch, o.flags, o.taps_hash, o.epi);
     }
 };
 std::mutex g_jit_mu;
@@ -465,6 +466,10 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         return nullptr;
     }
     char name[512];
+    if ((k.flags & kGeoSpark) && (k.flags & kGeoSparkReg))      // ... with the first FFT pass out of registers (cf32, W = 128 ... 1024)
+        snprintf(name, sizeof name, "qd::k_spark2<%d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.nco, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.lb, k.epi);
+    else
     if (k.flags & kGeoSpark)       // the wave-local kernel of chains without a lowpass: rch = chunks per tile
         snprintf(name, sizeof name, "qd::k_spark<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
                  k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb);
@@ -693,7 +698,8 @@ struct qd_plan {
     Geometry geo;
     chain_fn fn = nullptr, fn_unaligned = nullptr;
     const FixedEntry *fixed = nullptr;
-    uint32_t spark_ts = 0;               // ... its tile: samples per wave (512 or 1024)
+    uint32_t spark_ts = 0;               // ... its tile: samples per wave (512, 1024 or 2048)
+    int spark_lb = 4;                    // ... waves per SIMD it is register-budgeted for (= workgroups per CU)
     bool spark = false;                  // the wave-local kernel of chains without a lowpass (k_spark) is this plan's main kernel
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
@@ -1211,6 +1217,17 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         G = p->spark_ts / p->W;                // windows per wave tile (the kernel derives the same number from its tile size)
         p->nt = (int)(kSparkRow / spl_of(d.format));      // NCO rows of 512 samples: row table and lane table are laid out for that
         kflags = kGeoSpark;
+        p->spark_lb = spark_lb(p->spark_ts, p->nco);
+        if (jit_ok && d.format == QD_FMT_CF32 && (p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024)) {
+            // cf32, width 16 or 64 columns: the plan-time kernel that runs the base butterflies out of the row registers (k_spark2);
+            // tile = 64 lanes x 2 columns x base rows.  Cached builds always, a new one for streams of 1 GiB and more.
+            const uint32_t fbase = (ilog2(p->W) & 1) ? 8u : 16u, ts2 = 128u * fbase, g2 = ts2 / p->W;
+            const int lb2 = p->has_shift ? (fbase == 8 ? 3 : 2) : (fbase == 8 ? 4 : 3);
+            JitKey k{d.format, p->nco, 0, 0, 1, lb2, kThreads, p->W, p->S, 1, 0, g2, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkReg, 0ull, d.epilogue};
+            if (hipFunction_t f = jit_chain_kernel(k, &p->jit_note, may_compile)) {
+                p->jit_fn = f; p->spark_ts = ts2; G = g2; kflags |= kGeoSparkReg; p->spark_lb = lb2;
+            }
+        }
     } else {
         while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
         while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
@@ -1236,7 +1253,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         raw_elems = re_gen;
     }
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
-    if (p->spark) p->geo.lds_main = ((size_t)(p->W < 16 ? 16 : p->W) + 4 * (size_t)p->spark_ts) * 8;       // twiddles | four waves' transform buffers (k_spark)
+    if (p->spark) p->geo.lds_main = ((size_t)(p->W < 16 ? 16 : p->W) + 4 * (size_t)p->spark_ts) * 8 +     // twiddles | four waves' transform buffers (k_spark)
+                                    (((kflags & kGeoSparkReg) && p->has_shift) ? (size_t)kSparkRow * 16 : 0);   // k_spark2 with a shift: + the NCO lane table
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
@@ -1246,7 +1264,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (!p->fn || !p->fn_unaligned) return fail(QD_ERR_UNSUPPORTED, "no kernel built for this format (QD_DEV_FAST build?)");
     {
         // plan-time specialisation for shapes without a built-in FixedGeo kernel
-        if (p->spark && jit_ok) {
+        if (p->spark && jit_ok && !p->jit_fn) {
             // the same kernel with the width as a compile-time constant (butterfly loops unroll, one base butterfly instead of five,
             // index arithmetic folds): cached builds always, a new one for streams of 1 GiB and more.  Falls back to the built-in
             // runtime-width kernel — same tiling, same bytes.
@@ -1305,7 +1323,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     int by_lds = (int)(kLdsMax / (p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes));
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
-    if (p->spark) { const int by_regs = spark_lb(p->spark_ts, p->nco); if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
+    if (p->spark) { const int by_regs = p->spark_lb; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->launch_nt > kThreads) { int by_threads = 2048 / p->launch_nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
     if (tuned || heavy || auto_variant) { int by_regs = (jit_lb * 4 * 64) / p->launch_nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (tuned && tune[7] && (int)tune[7] < p->wg_per_cu) p->wg_per_cu = (int)tune[7];

@@ -756,12 +756,28 @@ def test_wave_local_kernel_equals_generic_and_oracle(engine, oracle, fmt, shift)
             if epi == engine.EPI_BUCKET2_U8 and W < 2:
                 continue
             kw = dict(shift_hz=shift, width=W, stride=W, epilogue=epi, rng=rng_)
-            p = engine.Plan(fmt, sr, n, **kw)
+            p = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_NO_PLAN_TIME, **kw)      # the built-in runtime-width kernel
             g = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_GENERIC, **kw)
             assert p.info.kernel_flags & 524288 and not (g.info.kernel_flags & 524288), (W, p.info.kernel_flags, g.info.kernel_flags)
+            assert p.info.kernel_kind == 1
             assert p.n_windows == g.n_windows
             a, b = p.run_host(data), g.run_host(data)
             assert np.array_equal(a, b), (fmt, shift, W, epi, int((a != b).sum()))
+            if fmt == 0 or W in (4, 64, 256):
+                # the plan-time builds (what a stream of 1 GiB and more gets): width as a compile-time constant, and for cf32 at
+                # W = 128 ... 1024 the kernel whose base butterflies run out of the row registers (bit 20)
+                j = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_SPECIALISE, **kw)
+                assert j.info.kernel_kind == 2 and j.info.kernel_flags & 524288
+                assert bool(j.info.kernel_flags & 1048576) == (fmt == 0 and W in (128, 256, 512, 1024)), (W, j.info.kernel_flags)
+                c = j.run_host(data)
+                assert np.array_equal(c, b), (fmt, shift, W, epi, "plan-time build", int((c != b).sum()))
+                if epi == engine.EPI_NORMS_F32:
+                    nwj = j.n_windows
+                    for w0 in sorted({0, min(nwj - 1, max(1, 512 // W)), min(nwj - 1, max(1, 2048 // W) + 1), nwj // 2}):
+                        first, count = j.src_range(w0, nwj - w0)
+                        sub = j.run_host(data[first * bps:(first + count) * bps], w0, nwj - w0, src_first=first)
+                        assert np.array_equal(sub, b[w0:]), (fmt, shift, W, w0, "plan-time build")
+                j.close()
             if epi == engine.EPI_NORMS_F32:
                 ref, _ = ch.spark_fft(W, W)
                 assert ref.shape == a.shape
@@ -798,14 +814,17 @@ def test_wave_local_kernel_many_tiles(engine, oracle):
     slab = bench.synth_slab(torch, 0, 0, n, 0x5EED0002, dev)
     host = slab.cpu().numpy().tobytes()
     for shift in (None, 280000):
-        p = engine.Plan(0, 21_000_000, n, shift_hz=shift, width=128, stride=128)
+        p = engine.Plan(0, 21_000_000, n, shift_hz=shift, width=128, stride=128, kernel_policy=_ffi.KERNEL_NO_PLAN_TIME)
         g = engine.Plan(0, 21_000_000, n, shift_hz=shift, width=128, stride=128, kernel_policy=_ffi.KERNEL_GENERIC)
-        assert p.info.kernel_flags & 524288
+        j = engine.Plan(0, 21_000_000, n, shift_hz=shift, width=128, stride=128, kernel_policy=_ffi.KERNEL_SPECIALISE)
+        assert p.info.kernel_flags & 524288 and j.info.kernel_flags & 1048576
         a = torch.empty(p.n_windows, 128, dtype=torch.float32, device=dev)
-        b = torch.empty_like(a)
-        p.run_device(slab, a); g.run_device(slab, b)
+        b, c = torch.empty_like(a), torch.empty_like(a)
+        p.run_device(slab, a); g.run_device(slab, b); j.run_device(slab, c)
         torch.cuda.synchronize()
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert torch.equal(c.view(torch.int32), b.view(torch.int32))
+        j.close()
         ch = oracle.Chain.from_bytes(host, 0, 21_000_000)
         if shift is not None:
             ch = ch.shift(shift)
