@@ -1257,13 +1257,15 @@ __device__ __forceinline__ void wave_bucket_epilogue_fn(const ChainParams &P, co
     }
 }
 
-template <class GeoT, uint32_t KB = 0 /* bucket epilogue: bins per lane the caller's buffer may hold (0: from the geometry) */>
+template <class GeoT, uint32_t KB = 0 /* bucket epilogue: bins per lane the caller's buffer may hold (0: from the geometry) */,
+          int PART = 0 /* 0: the whole transform + epilogue; 1: the base butterflies only; 2: the radix-4 layers + epilogue of windows whose base pass is done */>
 __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const GeoT &geo, const float2 *twl, float2 *fbp, uint64_t pw0, uint32_t pg, uint32_t tid) {
     uint32_t lane = tid & 63u;
     asm volatile("" : "+v"(lane));            // opaque: per-lane LDS / output addresses are rebuilt per tile, not hoisted out of the tile loop and spilled
     auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     const uint32_t base = geo.base_len, log_tpw = geo.logW - geo.log_base;
     const uint32_t n_task = pg << log_tpw;
+    if constexpr (PART != 2)
     for (uint32_t t = lane; t < n_task; t += 64) {
         float2 *d = fbp + (size_t)t * base;
         if (base == 16) {
@@ -1290,6 +1292,7 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
             d[0] = v0; d[1] = v1;
         }
     }
+    if constexpr (PART == 1) return;
     uint32_t cols = base, log_cols = geo.log_base;
     const float2 *tw = twl;
     for (uint32_t layer = 0; layer < geo.layers; ++layer) {
@@ -2792,7 +2795,7 @@ struct Pipe3S {
     static constexpr bool kWrite = (GeoT::kFlags & kGeoWriteSink) != 0;          // no FFT stage, no output ring
     static_assert(!kWrite || !kOverlap, "the write sink's sub-blocks lie side by side");
     static constexpr uint32_t kLdsBytes = kWrite ? RAW_ELEMS * 8 + ((T + 3) & ~3u) * 4
-                                                 : (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + G * W + W) * 8 + ((T + 3) & ~3u) * 4;
+                                                 : (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + 2 * G * W + W) * 8 + ((T + 3) & ~3u) * 4;      // two transform buffers: base pass of step s beside the layers of step s - 1
     static constexpr uint32_t kConsumerThreads = kWrite ? 256u : 512u;
 };
 
@@ -2814,8 +2817,8 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
     float2 *dec = raw + K::RAW_ELEMS, *trc = dec + DR;                             // trc exists for overlapping windows only
-    float2 *fbx = dec + (K::kOverlap ? 2u : 1u) * DR;
-    float2 *twl = fbx + (size_t)G * W;
+    float2 *fbx = dec + (K::kOverlap ? 2u : 1u) * DR;                              // two buffers of G W points, used alternately
+    float2 *twl = fbx + 2 * (size_t)G * W;
     float *tapl = reinterpret_cast<float *>(kWrite ? raw + K::RAW_ELEMS : twl + W);  // write sink: sample ring | taps, nothing else
     if (P.lds_dyn < K::kLdsBytes) return;                                              // host / kernel layout disagreement: leave the output untouched (the parity tests see it)
 
@@ -2836,7 +2839,7 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
     const uint64_t t_lo = (uint64_t)blockIdx.x * base_cnt + (blockIdx.x < rem ? blockIdx.x : rem);
     const uint32_t n_steps = (uint32_t)(base_cnt + (blockIdx.x < rem ? 1u : 0u));
     if (n_steps == 0) return;                                                      // uniform over the workgroup
-    const uint32_t n_iter = n_steps + (kWrite ? 2u : 3u);
+    const uint32_t n_iter = n_steps + (kWrite ? 2u : 4u);
     auto g_cnt_of = [&](uint64_t t) -> uint32_t {
         const uint64_t w0 = t * G, left = P.n_windows - w0;
         return left < G ? (uint32_t)left : G;
@@ -2952,7 +2955,16 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
                     const uint32_t drow = (q + geo.a0) % K::RINGD;
                     const float2 *rowp = raw + (size_t)drow * Dp;
                     float2 snap = make_float2(0.f, 0.f);
-                    const float2 full = fir_pair<GeoT, true>(rowp, jmax, tapl, &snap);
+                    // The taps sit behind the sample ring, ~150 KB into LDS — past the 16-bit offset field of a DS instruction.  Left as a
+                    // compile-time address, every one of the T/4 broadcast tap reads gets an address register of its own, materialised
+                    // in an SGPR outside the loop (a hundred of them, most spilled to lanes of a VGPR) and moved to a VGPR per read:
+                    // ~100 VALU + ~100 SALU instructions per pass on the wave whose pass IS the step's critical path.  One opaque base
+                    // register instead: every tap read is base + immediate.
+                    typedef const float __attribute__((address_space(3))) *lds_f32_p;
+                    uint32_t taps_off = (uint32_t)(uintptr_t)(lds_f32_p)tapl;            // the LDS byte offset, in a VGPR the compiler cannot see through
+                    asm volatile("" : "+v"(taps_off));
+                    const float *taps_v = (const float *)(lds_f32_p)(uintptr_t)taps_off;
+                    const float2 full = fir_pair<GeoT, true>(rowp, jmax, taps_v, &snap);
                     const uint32_t pos = q % DR;
                     if constexpr (kWrite) {
                         // do_write / LowPass::read_at output (src/lib.rs:206-209): the decimated cf32 samples themselves, in stream order
@@ -2971,34 +2983,54 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
             __syncthreads();
         }
     } else if constexpr (!kWrite) {
-        // ================= gather + FFT + |X| of step s = it - 3: wave v takes windows [v GV, (v + 1) GV) of the tile, all wave-local
+        // ================= the transform, two waves per role, each role on half of the tile's windows:
+        //   waves 0, 1: gather + the BASE butterflies of step s = it - 3 into transform buffer s & 1;
+        //   waves 2, 3: the radix-4 layers, |X| and the epilogue of step s = it - 4 out of buffer s & 1.
+        // Round 3 gave every wave G / 4 windows from gather to store: the sixteen-point base butterfly of a 64-point window is ONE
+        // task per quarter window, so each of the four waves walked its ~250 instructions with 16 of 64 lanes active (and the last
+        // wave with 8) — 1000 wave-instructions per step for work that fills 56 lanes once.  Split by ROLE a wave has twice the
+        // windows in the pass it runs (28 base tasks; 112 butterflies and 448 bins: two and seven full rounds) and the transform
+        // stage issues ~45 % fewer instructions per step; the price is one more step of latency per run and a second G W buffer.
         __builtin_amdgcn_s_setprio(1);
         const uint32_t v = wave - (PW + 4);
+        constexpr uint32_t GH = (G + 1) / 2;
+        const uint32_t g0 = (v & 1u) * GH;
+        uint32_t rot = 0;                                                          // (step mod 3) G S: where the step's outputs start in the output ring
         for (uint32_t it = 0; it < n_iter; ++it) {
-            if (it >= 3) {
-                const uint32_t s = it - 3;
+            if (v < 2) {
+                if (it >= 3 && it - 3 < n_steps) {
+                    const uint32_t s = it - 3;
+                    const uint32_t g_cnt = g_cnt_of(t_lo + s);
+                    const uint32_t g1 = (g0 + GH < g_cnt) ? g0 + GH : g_cnt;
+                    if (g0 < g1 && !QD_DBG(P, 128)) {
+                        float2 *fbw = fbx + (size_t)(s & 1u) * G * W + (size_t)g0 * W;
+                        uint32_t lane = tid & 63u;
+                        asm volatile("" : "+v"(lane));
+                        constexpr uint32_t log_width = 2 * GeoT::layers;
+                        const uint32_t n_o = (g1 - g0) << logW;
+                        for (uint32_t o = lane; o < n_o; o += 64) {
+                            const uint32_t gl_ = o >> logW, k = o & (W - 1);
+                            // ring position (s G S + g S + k) mod 3 G S: g S + k < 2 G S (Pipe3S::ok), the step's base rotates through 0, GS, 2GS
+                            uint32_t pos = rot + (g0 + gl_) * S + k;
+                            pos = pos >= DR ? pos - DR : pos;
+                            const bool tr = K::kOverlap && (W - k) * D + T / 2 < T;       // the window's truncated tail reads the snapshot ring (dec + DR)
+                            const float2 val = dec[pos + (tr ? DR : 0u)];
+                            const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                            fbw[(gl_ << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = val;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        wave_fft_epilogue_fn<GeoT, 0, 1>(P, geo, twl, fbw, 0, g1 - g0, tid);
+                    }
+                }
+                if (it >= 3) { rot += GS; rot = rot >= DR ? rot - DR : rot; }
+            } else if (it >= 4) {
+                const uint32_t s = it - 4;
                 const uint64_t t = t_lo + s;
                 const uint32_t g_cnt = g_cnt_of(t);
-                const uint32_t g0 = v * GV, g1 = (g0 + GV < g_cnt) ? g0 + GV : g_cnt;
-                if (g0 < g1 && !QD_DBG(P, 128)) {
-                    float2 *fbw = fbx + (size_t)g0 * W;
-                    uint32_t lane = tid & 63u;
-                    asm volatile("" : "+v"(lane));
-                    constexpr uint32_t log_width = 2 * GeoT::layers;
-                    const uint32_t n_o = (g1 - g0) << logW;
-                    const uint32_t q_base = s * GS;
-                    for (uint32_t o = lane; o < n_o; o += 64) {
-                        const uint32_t gl_ = o >> logW, k = o & (W - 1);
-                        const uint32_t pos = (q_base + (g0 + gl_) * S + k) % DR;
-                        const bool tr = K::kOverlap && (W - k) * D + T / 2 < T;
-                        const float2 val = tr ? trc[pos] : dec[pos];
-                        const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
-                        fbw[(gl_ << logW) + yy + (rev4(xx, geo.layers) << geo.log_base)] = val;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    wave_fft_epilogue_fn<GeoT>(P, geo, twl, fbw, P.first_window + t * G + g0, g1 - g0, tid);
-                }
+                const uint32_t g1 = (g0 + GH < g_cnt) ? g0 + GH : g_cnt;
+                if (g0 < g1 && !QD_DBG(P, 128))
+                    wave_fft_epilogue_fn<GeoT, (GH * W + 63) / 64, 2>(P, geo, twl, fbx + (size_t)(s & 1u) * G * W + (size_t)g0 * W, P.first_window + t * G + g0, g1 - g0, tid);
             }
             __syncthreads();
         }
