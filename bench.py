@@ -58,6 +58,8 @@ DEFAULT_WORKLOAD = "cfg3p"
 BPS = {0: 8, 1: 2, 2: 2, 3: 4}
 STREAM_SEED = 0x5EED0002     # ONE seed for the whole stream: the generator is keyed by absolute sample index, not by rank
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E data-sheet peak (MI355X_MICROARCH.md); ~6300 measured copy
+HBM_ACHIEVABLE_GBPS = 6290.0  # what a float4 copy streams on this part (MI355X_MICROARCH.md, chip-level parameters)
+SCLK_MAX_MHZ = 2400.0
 # VALU issue rates measured on MI355X at four waves per SIMD, chip unthrottled at 2.4 GHz (scripts/ubench_pk.hip,
 # profiles/r02/ubench_pk.log): ns per wave-instruction per SIMD.  A packed f32 op (two lane-operations) costs what an f64 op
 # costs and 5 % less than two scalar f32 ops, so the roof prices the FIR and the complex multiply as packed ops.
@@ -70,13 +72,17 @@ def valu_ops_per_sample(cfg, nco_order):
     lane-operations, packed f32 operations (two lane-operations each) and f64-rate operations.  FIR: T/D taps per input sample,
     one packed multiply and one packed add per tap (re and im, separately rounded); NCO: 9 (first order)
     / 12 (second order) f64 ops + 2 f64->f32 converts, complex multiply 3 packed ops; FFT ~5 W log2 W flops per window; |X| per
-    bin: 2 converts, f64 mul + fma, an IEEE f64 sqrt (= 18 f64 issue slots) and a convert; unpack per sample (two components):
+    bin: the short exact form (see below); unpack per sample (two components):
     8-bit ~10 f32 ops (convert, bias, multiply by the reciprocal, residual, correction), cs16 12."""
     fc, D, T = cfg["lp"]
     W, S = cfg["W"], cfg["S"]
     f32 = 5.0 * W * math.log2(W) / (S * D)
     pk = 2.0 * T / D
-    f64 = 23.0 * W / (S * D)
+    # |X| per bin (round 4, qd_device.h norm_fast): 10 f64-rate slots (3 converts up, multiply + fma, convert down, 2 converts of the
+    # seed, 2 fma of the Newton step, convert) and ~11 f32 slots (rsq = 4, two multiplies, five integer / compare operations for the
+    # IEEE-path test); round 3 priced the IEEE f64 square root at 23 f64-rate slots, which made the roof lower and the fraction higher
+    f64 = 10.0 * W / (S * D)
+    f32 += 11.0 * W / (S * D)
     if cfg["shift"] is not None:
         pk += 3.0
         f64 += (12.0 if nco_order == 2 else 9.0) + 2.0
@@ -451,7 +457,7 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
     finite = bool(torch.isfinite(out).all().item())
     power = None
     if rank == 0 and world == 1 and getattr(args, "power_sample", False):
-        power = sample_power(step, torch, max(1.0, 2.5))
+        power = sample_power(step, torch, getattr(args, "power_seconds", 2.5))
 
     res = None
     if rank == 0:
@@ -479,9 +485,12 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
                     traffic_profiled = {"hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "source": ent.get("source", "profiles/")}
             except Exception:
                 traffic_profiled = None
-        roof = {"bound": bound, "kernel": "qd::k_chain", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+        roof = {"bound": bound, "kernel": plan.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                 "traffic": None, "traffic_profiled": traffic_profiled,
-                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac},
+                # frac_of_achievable: against what a copy kernel streams on this part (MI355X_MICROARCH.md: 6.29 TB/s), beside — never
+                # instead of — the data-sheet fraction
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac,
+                        "achievable_peak": HBM_ACHIEVABLE_GBPS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS},
                 "valu": {"achieved": kernel_msamples, "peak": valu_ms_roof, "unit": "Msamples/s", "frac": valu_frac,
                          "f32_ops_per_sample": f32_ops, "f64_ops_per_sample": f64_ops,
                          "issue_ns_per_wave_instr": {"f32": T_F32_NS, "f64": T_F64_NS, "packed_f32": T_PK_NS},
@@ -496,6 +505,13 @@ def measure(args, name, cfg, rank, world, device, dist, steps, warmup, with_cpu)
             roof.update(achieved=kernel_msamples * 1e6 * flops / 1e12, peak=valu_ms_roof * 1e6 * flops / 1e12, unit="TFLOP/s", frac=valu_frac)
         if power:
             roof["power"] = power
+            # the VALU roof at the shader clock the board actually held under this kernel (the issue rates above are per-instruction times at
+            # an unthrottled 2.4 GHz; at the package power cap the governor runs the kernel well below that): peak_at_sclk = peak x sclk / 2400
+            if power.get("sclk_mhz_mean"):
+                scale = power["sclk_mhz_mean"] / SCLK_MAX_MHZ
+                roof["valu"]["sclk_mhz"] = power["sclk_mhz_mean"]
+                roof["valu"]["peak_at_sclk"] = valu_ms_roof * scale
+                roof["valu"]["frac_at_sclk"] = kernel_msamples / (valu_ms_roof * scale)
         res = {"workload": name, "value": samples_total / (elapsed / steps) / 1e6, "ms_per_step": ms_per_step, "roofline": roof,
                "outputs_finite": finite, "seams_verified": seams,
                "halo_exchange": None if world == 1 or args.rehearse else {"bytes_per_rank": me.halo * bps, "ms": exchange_ms, "note": "one neighbour send/recv, once per resident slab, outside the timed steps"},
@@ -583,6 +599,41 @@ def write_sink_leg(cfg, device, steps=8):
            "hbm_frac": (in_b + out_b) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "outputs_finite": bool(torch.isfinite(out).all().item())}
     p.close()
     del slab, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def no_lowpass_leg(device, steps=6):
+    """Chains WITHOUT a lowpass (`from F [shift] sparkfft`, README example 1 / BASELINE configs[0]'s chain at scale; informational, never
+    `value`): 16 GiB cf32, stride == width, on the wave-local kernels (k_spark / k_spark2).  Every input sample is an FFT input and every
+    sample yields one f32 norm, so the algorithmic bytes are 8 read + 4 written per sample; fractions are of the 8 TB/s data-sheet peak
+    and of the 6.29 TB/s a copy kernel streams."""
+    import torch
+    import quadrs_amd as Q
+    n = 1 << 31
+    slab = synth_slab(torch, 0, 0, n, STREAM_SEED, device)
+    res = {"stream": "16 GiB cf32 @21 Msps, stride == width", "unit": "ms per pass", "shapes": {}}
+    for label, shift, W in (("w128", None, 128), ("shift_w128", 280000, 128), ("w1024", None, 1024)):
+        p = Q.Plan(0, 21_000_000, n, shift_hz=shift, width=W, stride=W)
+        out = torch.empty(p.n_windows, W, dtype=torch.float32, device=device)
+        for _ in range(2):
+            p.run_device(slab, out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            p.run_device(slab, out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        byts = n * 8 + out.numel() * 4
+        res["shapes"][label] = {"chain": f"{'shift 280000 -> ' if shift else ''}sparkfft -width {W}", "ms": ms, "Msamples_per_s": n / (ms * 1e-3) / 1e6,
+                                "GBps_read_plus_written": byts / (ms * 1e-3) / 1e9, "hbm_frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "frac_of_achievable": byts / (ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS, "kernel": p.kernel_name(),
+                                "kernel_kind": int(p.info.kernel_kind), "kernel_flags": int(p.info.kernel_flags), "outputs_finite": bool(torch.isfinite(out).all().item())}
+        p.close()
+        del out
+    del slab
     torch.cuda.empty_cache()
     return res
 
@@ -716,22 +767,29 @@ def main():
     main_res = measure(args, args.workload, cfg, rank, world, device, dist, args.steps, args.warmup,
                        with_cpu=(world == 1 and not args.no_cpu_baseline))
     args.power_sample = False
+    bad = rank == 0 and (main_res.get("seams_verified") is False or not main_res["outputs_finite"])
     others = None
     if args.workload == DEFAULT_WORKLOAD and not args.no_others and (world > 1 or args.samples_log2 is None):
         # the other BASELINE configs, briefly (same protocol, fewer steps, no CPU leg): parity-test cases first, bench lines second.
         # One GPU: configs[1..3]; several GPUs: configs[4] (the cfg3 chain on a cf32 stream sharded over the ranks).
         others = {}
-        for name in (("cfg2", "cfg3", "cfg4") if world == 1 else ("cfg5",)):
+        args.power_sample = world == 1 and not args.no_power
+        args.power_seconds = 1.0
+        for name in (("cfg2", "cfg3", "cfg4", "cfg5") if world == 1 else ("cfg5",)):
             ocfg = dict(WORKLOADS[name])
             if args.samples_log2 is not None:
                 ocfg["n"] = 1 << args.samples_log2
             r = measure(args, name, ocfg, rank, world, device, dist, 8, 2, with_cpu=False)
             if rank != 0:
                 continue
+            bad = bad or r.get("seams_verified") is False or not r["outputs_finite"]
+            pw = r["roofline"].get("power") or {}
             others[name] = {"value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"], "steps": 8, "warmup": 2,
                             "bound": r["roofline"]["bound"], "hbm_frac": r["roofline"]["hbm"]["frac"], "valu_frac": r["roofline"]["valu"]["frac"],
-                            "kernel_ms": r["roofline"]["kernel_ms"], "config": workload_desc(ocfg),
+                            "valu_frac_at_sclk": r["roofline"]["valu"].get("frac_at_sclk"), "sclk_mhz": pw.get("sclk_mhz_mean"), "watts": pw.get("watts_mean"),
+                            "kernel": r["roofline"]["kernel"], "kernel_ms": r["roofline"]["kernel_ms"], "config": workload_desc(ocfg),
                             **({"seams_verified": r["seams_verified"]} if r.get("seams_verified") is not None else {})}
+        args.power_sample = False
     if rank == 0:
         line = {
             "metric": "Msamples/s through shift->FIR->FFT chain",
@@ -772,6 +830,11 @@ def main():
                 line["write_sink"] = {"error": str(e)[:200]}
         if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
             try:
+                line["no_lowpass"] = no_lowpass_leg(device)
+            except Exception as e:                       # informational leg
+                line["no_lowpass"] = {"error": str(e)[:200]}
+        if world == 1 and args.workload == DEFAULT_WORKLOAD and args.samples_log2 is None and not args.no_others:
+            try:
                 line["end_to_end"] = end_to_end_host(device)
             except Exception as e:                       # the PCIe leg never takes the bench line down
                 line["end_to_end"] = {"error": str(e)[:200]}
@@ -779,6 +842,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        # a line whose seams did not verify or whose outputs are not finite is printed (it says so) but the run FAILS
+        sys.stderr.write("bench.py: seams_verified false or non-finite outputs: failing the run\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

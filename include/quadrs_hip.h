@@ -160,7 +160,8 @@ typedef struct {
     uint32_t kernel_kind;     /* 0 generic (runtime geometry), 1 built-in shape-specialised, 2 specialised at plan time (hiprtc) */
     uint32_t kernel_flags;    /* variant bits of the main kernel (0 for the generic kernels): 4 packed lane-per-output FIR, 8 row-aligned
                                  phase 1, 32 straight-line shared FIR, 64 deferred FFT, 128 packed two-output FIR, 256 non-temporal stream loads (65536: only rows no other tile reads), 8192 half-window tiles, 16384 fused FIR (QD_MODE_FAST),
-                                 32768 three-stage kernel (producer / FIR / FFT waves on consecutive tiles), 131072 its streaming form (runs of tiles, state carried in LDS), 262144 the streaming kernel as the write sink (QD_EPI_CF32_BLOCKS: producers + FIR waves, no FFT stage);
+                                 32768 three-stage kernel (producer / FIR / FFT waves on consecutive tiles), 131072 its streaming form (runs of tiles, state carried in LDS), 262144 the streaming kernel as the write sink (QD_EPI_CF32_BLOCKS: producers + FIR waves, no FFT stage),
+                                 524288 the wave-local kernel of chains WITHOUT a lowpass (stride == width: one wave per tile, no workgroup barriers), 1048576 its form with the base butterflies out of the row registers (cf32, W = 128 ... 1024; plan-time builds);
                                  chosen from the chain's geometry at plan time (built-in kernels: the same predicates, fixed at build time) */
     uint32_t _reserved;
 } qd_plan_info;
@@ -201,6 +202,9 @@ int qd_plan_destroy(qd_plan *plan);
 int qd_plan_get_info(const qd_plan *plan, qd_plan_info *info);
 /* taps the plan designed (T floats), for inspection */
 int qd_plan_get_taps(const qd_plan *plan, float *taps, size_t cap);
+/* the main kernel's name as a profiler lists it (template name with its geometry, e.g. "qd::k_chain_pipe3s<0, 1, FixedGeo<64, 16, 32, 400, 14, ...>, ...>"),
+ * NUL-terminated into buf[cap]; reporting only (bench.py's roofline.kernel) */
+int qd_plan_kernel_name(const qd_plan *plan, char *buf, size_t cap);
 
 /* source samples [*first, *first + *count) that windows [first_window, first_window+n) read */
 int qd_plan_src_range(const qd_plan *plan, uint64_t first_window, uint64_t n_windows,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "qd_device_alloc", "qd_device_free", "qd_device_copy",
     "qd_set_stream", "qd_release_workspaces", "qd_plan_create_ex", "qd_plan_shard_info", "qd_plan_run_sharded",
     "qd_plan_run_sharded_device", "qd_plan_get_stats", "qd_host_alloc", "qd_host_free", "qd_host_register",
-    "qd_host_unregister",
+    "qd_host_unregister", "qd_plan_kernel_name",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
             "qd_plan_destroy": (i32, [vp]),
             "qd_plan_get_info": (i32, [vp, C.POINTER(PlanInfo)]),
             "qd_plan_get_taps": (i32, [vp, vp, sz]),
+            "qd_plan_kernel_name": (i32, [vp, C.c_char_p, sz]),
             "qd_plan_src_range": (i32, [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]),
             "qd_plan_run": (i32, [vp, vp, i32, u64, u64, u64, u64, vp, i32, vp]),
             "qd_plan_set_timing": (i32, [vp, i32]),

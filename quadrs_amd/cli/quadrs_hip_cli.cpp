@@ -400,7 +400,9 @@ struct DeviceBuf {
 
 // sparkfft / bucket through ONE fused plan over the whole file — or over a `gen` stream that is produced on the device
 // (src/gen.rs:30-47) and never crosses PCIe: only the glyph codes / digits come back
-void run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
+// returns false when the library has no fused plan for the chain (QD_ERR_UNSUPPORTED: e.g. overlapping windows whose FIR input exceeds one
+// workgroup's LDS); the header line is printed by then, the caller pulls the windows through the iterator chain instead
+bool run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
     const bool from_gen = cs.src->kind == OP_GEN;
     std::unique_ptr<MappedFile> data;
     if (!from_gen) data.reset(new MappedFile(cs.src->filename));
@@ -416,7 +418,11 @@ void run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
     d.has_range = sink.has_range; d.range_min = sink.rmin; d.range_max = sink.rmax;
     if (sink.kind == OP_SPARKFFT) printf("sparkfft sample_rate=%" PRIu64 "\n", out_rate);   // printed before any read (src/fft.rs:19)
     qd_plan *plan = nullptr;
-    qd_check(from_gen ? qd_plan_create(&d, &plan) : create_plan(d, &plan), "plan");
+    {
+        const int rc = from_gen ? qd_plan_create(&d, &plan) : create_plan(d, &plan);
+        if (rc == QD_ERR_UNSUPPORTED) return false;
+        qd_check(rc, "plan");
+    }
     qd_plan_info info;
     qd_check(qd_plan_get_info(plan, &info), "plan info");
     std::vector<uint8_t> out(info.n_windows * info.out_bytes_per_window + 1);
@@ -458,6 +464,7 @@ void run_fused(const ChainSpec &cs, const Op &sink, uint64_t out_rate) {
         for (uint64_t w = 0; w < info.n_windows; ++w) digits.push_back((char)('0' + out[w]));
         printf("%s\n", digits.c_str());                                   // src/lib.rs:144-158
     }
+    return true;
 }
 
 // FFT + epilogue of nb gathered windows (contiguous, stride W) on the GPU: a no-shift/no-lowpass plan
@@ -483,9 +490,9 @@ std::vector<uint8_t> sink_batch(const qd_c32 *buf, uint64_t nb, size_t W, const 
 
 // the same sinks over an arbitrary iterator chain: windows are pulled through read_exact_at exactly as
 // the reference does (src/fft.rs:30,91), gathered, and transformed in batches on the GPU
-void run_iter_sink(const Samples &s, const Op &sink) {
+void run_iter_sink(const Samples &s, const Op &sink, bool header_printed = false) {
     const size_t W = sink.width; const uint64_t S = sink.stride;
-    if (sink.kind == OP_SPARKFFT) printf("sparkfft sample_rate=%" PRIu64 "\n", s.sample_rate());
+    if (sink.kind == OP_SPARKFFT && !header_printed) printf("sparkfft sample_rate=%" PRIu64 "\n", s.sample_rate());
     if (!W || (W & (W - 1))) bail("Radix4 algorithm requires a power-of-two input size");
     if (S == 0) bail("stride 0 never terminates");
     uint64_t len = s.len();
@@ -646,8 +653,9 @@ int main(int argc, char **argv) {
             case OP_BUCKET:
                 if (!samples) bail(op.kind == OP_SPARKFFT ? "sparkfft requires an input" : "bucket -by freq requires an input");
                 if (op.kind == OP_BUCKET && op.levels != 2) bail("only supporting two levels for now");
-                if (cs.fusable && chain_clean && !getenv("QUADRS_HIP_NO_FUSE")) run_fused(cs, op, samples->sample_rate());
-                else run_iter_sink(*samples, op);
+                if (cs.fusable && chain_clean && !getenv("QUADRS_HIP_NO_FUSE")) {
+                    if (!run_fused(cs, op, samples->sample_rate())) run_iter_sink(*samples, op, true);
+                } else run_iter_sink(*samples, op);
                 break;
             case OP_WRITE:
                 if (!samples) bail("write requires an input");

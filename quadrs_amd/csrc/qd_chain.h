@@ -2811,7 +2811,6 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
     constexpr uint32_t PT = PT_, NTHR = PT_ + K::kConsumerThreads, PW = PT_ / 64;                    // producer waves [0, PW), FIR waves [PW, PW + 4), FFT waves [PW + 4, PW + 8)
     constexpr uint32_t W = K::W, S = K::S, D = K::D, T = K::T, G = K::G, Dp = K::Dp, logW = GeoT::logW;
     constexpr uint32_t ROW = K::ROW, ROWB = ROW * FT::BPS, VECB = SPL * FT::BPS, RN = K::RN, RR = K::RR, GS = K::GS, DR = K::DR;
-    constexpr uint32_t GV = (G + 3) / 4;
     const GeoT geo(P);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];

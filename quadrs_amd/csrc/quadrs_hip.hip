@@ -722,6 +722,14 @@ struct qd_plan {
     size_t stage_in_bytes = 0, stage_out_bytes = 0, pin_in_bytes = 0, pin_out_bytes = 0;
     hipStream_t streams[2] = {nullptr, nullptr};
     qd_plan_stats stats{};
+    // composite plans (a window whose FIR input W*D + T exceeds the 160 KiB LDS tile, stride == width): stage A filters and decimates the
+    // stream in read_at blocks of W outputs (the write sink's kernels: per-block truncation == the sink's per-window truncation,
+    // src/filter.rs:68-83), stage B transforms the W-point windows of that decimated stream; `cmp_tmp` carries it through HBM
+    qd_plan *cmp_a = nullptr, *cmp_b = nullptr;
+    void *cmp_tmp = nullptr, *cmp_in = nullptr, *cmp_out = nullptr;
+    size_t cmp_tmp_bytes = 0, cmp_in_bytes = 0, cmp_out_bytes = 0;
+    hipEvent_t cmp_done = nullptr;
+    bool cmp_used = false;
     // sharded plans (options.n_shards > 1): one child plan per shard, created on that shard's device
     std::vector<qd_plan *> shards;
     std::vector<qd_shard_info> shard_info;
@@ -983,6 +991,7 @@ int qd_lowpass_design(uint64_t frequency, uint64_t sample_rate, size_t size, flo
 }
 
 int qd_plan_destroy(qd_plan *p);
+constexpr int kNeedComposite = 1000;       // plan_init -> qd_plan_create_ex: build the two-stage plan (never leaves the library)
 
 static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t rate) {
     (void)hipGetDevice(&p->device);
@@ -992,10 +1001,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (d.epilogue == QD_EPI_CF32_BLOCKS) {          // tiles are sub-blocks of <= 256 outputs of a read_at block of d.width
         p->blk_len = (uint32_t)d.width;
         p->W = p->blk_len < 256 ? p->blk_len : 256;
-        p->logW = ilog2(p->W); p->S = p->W;
-        p->blk_subs = p->blk_len / p->W;
         const uint32_t c = (uint32_t)(d.taps - d.taps / 2);
         p->tile_extra = c > d.decimate ? c - (uint32_t)d.decimate : 0;
+        // a sub-block's FIR input (W D + T + extra samples) must fit the LDS tile: long decimations take shorter sub-blocks
+        while (p->W > 1 && lds_for(1, p->W, p->W, (uint64_t)d.decimate, d.taps + p->tile_extra, nullptr, 1, 1, d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8) > kLdsMax) p->W /= 2;
+        p->logW = ilog2(p->W); p->S = p->W;
+        p->blk_subs = p->blk_len / p->W;
     }
     p->D = p->has_fir ? (uint32_t)d.decimate : 1;
     p->T = p->has_fir ? (uint32_t)d.taps : 0;
@@ -1017,9 +1028,13 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // tile geometry: a shape-specialised kernel dictates G; otherwise pick G for LDS / lane use
     uint32_t G = 1, raw_elems = 0;
     const uint32_t T_lds = p->T + p->tile_extra;     // LDS sizing sees the extended tile
-    if (lds_for(1, p->W, p->S, p->D, T_lds, &raw_elems, 1, 1, d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8) > kLdsMax)
-        return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile",
+    if (lds_for(1, p->W, p->S, p->D, T_lds, &raw_elems, 1, 1, d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8) > kLdsMax) {
+        // LowPass::read_at allocates whatever buf.len() * D + T asks for (src/filter.rs:68-69); one workgroup's LDS does not.  Windows that
+        // lie side by side run as a two-stage (composite) plan instead — qd_plan_create_ex builds it on this status
+        if (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && p->S == p->W) return kNeedComposite;
+        return fail(QD_ERR_UNSUPPORTED, "one window (W*D+T = %llu samples) exceeds the 160 KiB LDS tile and the windows overlap or leave gaps (stride != width)",
                     (unsigned long long)((uint64_t)d.width * (d.has_lowpass ? d.decimate : 1) + (d.has_lowpass ? d.taps : 0)));
+    }
     p->fixed = (p->has_fir && d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC) ? find_fixed(d.format, p->nco, p->W, p->S, p->D, p->T) : nullptr;
     // qd_plan_options.tile_hint = {G, NT, FIRR, FIRB, LB, PAD}: force a plan-time build with this tiling instead of the table /
     // heuristics (LB = waves per SIMD the build is register-budgeted for: 4 -> 128 VGPRs, 2 -> 256; PAD = LDS pad elements per row)
@@ -1453,6 +1468,30 @@ int qd_plan_create_ex(const qd_chain_desc *desc, const qd_plan_options *options,
     p->d = d;
     p->opt = opt;
     int rc = plan_init(p, d, len, rate);
+    if (rc == kNeedComposite) {
+        if (opt.n_shards > 1) rc = fail(QD_ERR_UNSUPPORTED, "a window larger than the LDS tile runs as a two-stage plan, which is not sharded inside one process");
+        else {
+            qd_plan_options copt = opt;
+            copt.n_shards = 0;
+            memset(copt.tile_hint, 0, sizeof copt.tile_hint);
+            qd_chain_desc a = d;                         // stage A: the same source chain into read_at blocks of W decimated samples
+            a.stride = d.width; a.epilogue = QD_EPI_CF32_BLOCKS; a.has_range = 0;
+            rc = qd_plan_create_ex(&a, &copt, &p->cmp_a);
+            if (rc == QD_OK) {
+                qd_chain_desc b{};                       // stage B: W-point windows side by side over the decimated stream
+                b.struct_size = sizeof b;
+                b.format = QD_FMT_CF32; b.sample_rate = rate ? rate : 1;
+                b.n_samples = d.epilogue == QD_EPI_BUCKET2_U8 ? (p->n_windows + 1) * d.width : p->n_windows * d.width + 1;      // exactly n_windows windows (src/fft.rs:28,65 / :86)
+                b.width = d.width; b.stride = d.width; b.epilogue = d.epilogue; b.mode = d.mode;
+                b.has_range = d.has_range; b.range_min = d.range_min; b.range_max = d.range_max;
+                rc = qd_plan_create_ex(&b, &copt, &p->cmp_b);
+            }
+            if (rc == QD_OK && (p->cmp_a->n_windows < p->n_windows || p->cmp_b->n_windows != p->n_windows))
+                rc = fail(QD_ERR_UNSUPPORTED, "two-stage plan: stage window counts disagree (%llu blocks, %llu / %llu windows)", (unsigned long long)p->cmp_a->n_windows,
+                          (unsigned long long)p->cmp_b->n_windows, (unsigned long long)p->n_windows);
+            p->geo.G = 1;
+        }
+    }
     if (rc) { qd_plan_destroy(p); return rc; }
     // sharded plans: the parent describes the whole stream; each shard gets a plan of its own on its device
     const uint32_t n_shards = opt.n_shards > 1 ? opt.n_shards : 1;
@@ -1481,8 +1520,13 @@ int qd_plan_destroy(qd_plan *p) {
     if (!p) return QD_OK;
     for (qd_plan *c : p->shards) (void)qd_plan_destroy(c);
     p->shards.clear();
+    if (p->cmp_a) (void)qd_plan_destroy(p->cmp_a);
+    if (p->cmp_b) (void)qd_plan_destroy(p->cmp_b);
+    p->cmp_a = p->cmp_b = nullptr;
     DeviceGuard guard(p->device);
     (void)hipDeviceSynchronize();
+    for (void *q : {p->cmp_tmp, p->cmp_in, p->cmp_out}) if (q) (void)hipFree(q);
+    if (p->cmp_done) (void)hipEventDestroy(p->cmp_done);
     free_streaming(p);
     if (p->taps_d) (void)hipFree(p->taps_d);
     if (p->tw_d) (void)hipFree(p->tw_d);
@@ -1505,6 +1549,13 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->raw_step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D;
     info->ratio = p->ratio;
     info->tile_windows = p->geo.G;
+    if (p->cmp_a) {                                   // two-stage plan: the kernel figures are stage A's (the filter)
+        qd_plan_info ia;
+        const int rc = qd_plan_get_info(p->cmp_a, &ia);
+        if (rc) return rc;
+        info->threads = ia.threads; info->lds_bytes = ia.lds_bytes; info->kernel_kind = ia.kernel_kind; info->kernel_flags = ia.kernel_flags;
+        return QD_OK;
+    }
     info->threads = (uint32_t)p->launch_nt;
     info->lds_bytes = (uint32_t)(p->geo.lds_main ? p->geo.lds_main : p->geo.lds_bytes);
     info->kernel_kind = p->jit_fn ? 2u : ((p->fixed || p->spark) ? 1u : 0u);
@@ -1513,8 +1564,32 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     return QD_OK;
 }
 
+int qd_plan_kernel_name(const qd_plan *p, char *buf, size_t cap) {
+    if (!p || !buf || cap == 0) return fail(QD_ERR_INVALID, "plan/buf is NULL");
+    if (p->cmp_a) {
+        char a[256], b[256];
+        (void)qd_plan_kernel_name(p->cmp_a, a, sizeof a); (void)qd_plan_kernel_name(p->cmp_b, b, sizeof b);
+        snprintf(buf, cap, "two stages: %s | %s", a, b);
+        return QD_OK;
+    }
+    const int fmt = p->d.format;
+    char geo[160];
+    if (p->jit_fn || p->fixed)
+        snprintf(geo, sizeof geo, "FixedGeo<%u, %u, %u, %u, %u, ..., %u>", p->W, p->S, p->D, p->T, p->geo.G, p->kflags);
+    else snprintf(geo, sizeof geo, "DynGeo");
+    const char *kn = (p->kflags & kGeoSparkReg) && p->jit_fn ? "qd::k_spark2"
+                   : p->spark ? "qd::k_spark"
+                   : ((p->kflags & kGeoPipe3) && (p->kflags & kGeoStream) && (p->jit_fn || p->fixed)) ? "qd::k_chain_pipe3s"
+                   : ((p->kflags & kGeoPipe3) && (p->jit_fn || p->fixed)) ? "qd::k_chain_pipe3"
+                   : ((p->kflags & kGeoPipe) && p->jit_fn) ? "qd::k_chain_pipe" : "qd::k_chain";
+    snprintf(buf, cap, "%s<fmt %d, nco %d, %s>, %d threads, %s", kn, fmt, p->nco, geo, p->launch_nt,
+             p->jit_fn ? "plan-time build" : (p->fixed || p->spark ? "built-in" : "generic"));
+    return QD_OK;
+}
+
 int qd_plan_get_taps(const qd_plan *p, float *taps, size_t cap) {
     if (!p || !taps) return fail(QD_ERR_INVALID, "plan/taps is NULL");
+    if (p->cmp_a) return qd_plan_get_taps(p->cmp_a, taps, cap);
     if (cap < p->taps_h.size()) return fail(QD_ERR_INVALID, "taps buffer too small");
     if (!p->taps_h.empty()) memcpy(taps, p->taps_h.data(), p->taps_h.size() * sizeof(float));
     return QD_OK;
@@ -1532,11 +1607,19 @@ int qd_plan_src_range(const qd_plan *p, uint64_t first_window, uint64_t n_window
 int qd_plan_set_timing(qd_plan *p, int enabled) {
     if (!p) return fail(QD_ERR_INVALID, "plan is NULL");
     p->timing = enabled != 0;
+    if (p->cmp_a) { p->cmp_a->timing = p->timing; p->cmp_b->timing = p->timing; }
     return QD_OK;
 }
 
 int qd_plan_last_kernel_ms(qd_plan *p, float *ms) {
     if (!p || !ms) return fail(QD_ERR_INVALID, "NULL argument");
+    if (p->cmp_a) {
+        float a = 0.f, b = 0.f;
+        int rc = qd_plan_last_kernel_ms(p->cmp_a, &a);
+        if (rc == QD_OK) rc = qd_plan_last_kernel_ms(p->cmp_b, &b);
+        *ms = a + b;
+        return rc;
+    }
     if (!p->ev_recorded) return fail(QD_ERR_INVALID, "no timed run recorded");
     HIPCHK(hipEventSynchronize(p->ev1));
     HIPCHK(hipEventElapsedTime(ms, p->ev0, p->ev1));
@@ -1670,6 +1753,65 @@ int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint6
 }
 }  // namespace
 
+namespace {
+int grow(void **buf, size_t *have, size_t need) {
+    if (need <= *have) return QD_OK;
+    if (*buf) { HIPCHK(hipFree(*buf)); *buf = nullptr; *have = 0; }       // (hipFree waits for the device)
+    HIPCHK(hipMalloc(buf, need));
+    *have = need;
+    return QD_OK;
+}
+
+// windows [w0, w0 + nw) of a two-stage plan on device buffers: A filters blocks into the carrier, B transforms them; one stream, in order
+int composite_device(qd_plan *p, const void *src_d, uint64_t src_first, uint64_t src_count, uint64_t w0, uint64_t nw, void *out_d, hipStream_t st) {
+    qd_plan *a = p->cmp_a, *b = p->cmp_b;
+    const uint64_t W = p->W;
+    int rc = grow(&p->cmp_tmp, &p->cmp_tmp_bytes, (size_t)(nw * W + 16) * 8);
+    if (rc) return rc;
+    // the carrier is shared by every call on this plan: a call on another stream waits for the previous one's last kernel
+    if (p->cmp_used) HIPCHK(hipStreamWaitEvent(st, p->cmp_done, 0));
+    rc = launch_chain(a, &a->tabs_dev, src_d, src_first, src_count, w0 * a->blk_subs, nw * a->blk_subs, w0 * a->blk_subs, p->cmp_tmp, st);
+    if (rc) return rc;
+    rc = launch_chain(b, &b->tabs_dev, p->cmp_tmp, w0 * W, nw * W, w0, nw, w0, out_d, st);
+    if (rc) return rc;
+    if (!p->cmp_done) HIPCHK(hipEventCreateWithFlags(&p->cmp_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(p->cmp_done, st));
+    p->cmp_used = true;
+    return QD_OK;
+}
+
+int run_composite(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint64_t src_count, uint64_t first_window, uint64_t n_windows,
+                  void *out, int out_mem, hipStream_t st) {
+    if (n_windows == 0) return QD_OK;
+    if (src_mem == QD_MEM_DEVICE && out_mem == QD_MEM_DEVICE) return composite_device(p, src, src_first, src_count, first_window, n_windows, out, st);
+    if (!host_kind(src_mem) || !host_kind(out_mem))
+        return fail(QD_ERR_UNSUPPORTED, "mixed host/device buffers are not supported; use both host or both device");
+    // host-resident stream: plain chunks (copy in, two launches, copy out) — this path serves windows of tens of thousands of source
+    // samples, where a chunk is a handful of windows; no double buffering
+    const int bps = bps_of(p->d.format);
+    const uint64_t step = (uint64_t)p->W * p->D, rpw = step + p->T, obw = out_bytes_per_window(p);
+    uint64_t cw = (64ull << 20) / (step * bps);
+    if (cw < 1) cw = 1;
+    if (cw > n_windows) cw = n_windows;
+    int rc = grow(&p->cmp_in, &p->cmp_in_bytes, (size_t)(((cw - 1) * step + rpw) * bps + 64));
+    if (rc == QD_OK) rc = grow(&p->cmp_out, &p->cmp_out_bytes, (size_t)(cw * obw + 64));
+    if (rc) return rc;
+    for (uint64_t w = first_window; w < first_window + n_windows; w += cw) {
+        const uint64_t nw = std::min<uint64_t>(cw, first_window + n_windows - w);
+        const uint64_t s0 = w * step, sc = (nw - 1) * step + rpw;
+        if (s0 < src_first || s0 + sc > src_first + src_count)
+            return fail(QD_ERR_INVALID, "src slab [%llu,+%llu) does not cover samples [%llu,+%llu) needed by windows [%llu,+%llu)", (unsigned long long)src_first,
+                        (unsigned long long)src_count, (unsigned long long)s0, (unsigned long long)sc, (unsigned long long)w, (unsigned long long)nw);
+        HIPCHK(hipMemcpyAsync(p->cmp_in, static_cast<const uint8_t *>(src) + (s0 - src_first) * bps, (size_t)(sc * bps), hipMemcpyHostToDevice, st));
+        rc = composite_device(p, p->cmp_in, s0, sc, w, nw, p->cmp_out, st);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(static_cast<uint8_t *>(out) + (w - first_window) * obw, p->cmp_out, (size_t)(nw * obw), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return QD_OK;
+}
+}  // namespace
+
 int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint64_t src_count,
                 uint64_t first_window, uint64_t n_windows, void *out, int out_mem, void *stream) {
     if (!p || !src || !out) return fail(QD_ERR_INVALID, "NULL argument");
@@ -1681,6 +1823,7 @@ int qd_plan_run(qd_plan *p, const void *src, int src_mem, uint64_t src_first, ui
     std::lock_guard<std::mutex> lock(p->mu);
     DeviceGuard guard(p->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->cmp_a) return run_composite(p, src, src_mem, src_first, src_count, first_window, n_windows, out, out_mem, st);
     if (src_mem == QD_MEM_DEVICE && out_mem == QD_MEM_DEVICE)
         return launch_chain(p, &p->tabs_dev, src, src_first, src_count, first_window * subs, n_windows * subs, first_window * subs, out, st);
     if (!host_kind(src_mem) || !host_kind(out_mem))
@@ -1735,6 +1878,7 @@ int qd_plan_run_sharded(qd_plan *p, const void *src, int src_mem, void *out, int
 
 int qd_plan_run_sharded_device(qd_plan *p, void *const *slabs, void *const *outs, int sync) {
     if (!p || !slabs || !outs) return fail(QD_ERR_INVALID, "NULL argument");
+    if (p->cmp_a) return fail(QD_ERR_UNSUPPORTED, "a two-stage plan (window larger than the LDS tile) has no pre-split device path");
     const size_t n = p->shard_info.size();
     const int bps = bps_of(p->d.format);
     std::vector<qd_plan *> plans(n, p);

@@ -234,6 +234,12 @@ class Plan:
             check(lib().qd_plan_get_taps(self._h, _np_ptr(out), out.size))
         return out
 
+    def kernel_name(self):
+        """the main kernel's name as rocprofv3 lists it (qd_plan_kernel_name)"""
+        buf = C.create_string_buffer(512)
+        check(lib().qd_plan_kernel_name(self._h, buf, 512))
+        return buf.value.decode()
+
     def src_range(self, first_window, n_windows):
         a, b = C.c_uint64(), C.c_uint64()
         check(lib().qd_plan_src_range(self._h, first_window, n_windows, C.byref(a), C.byref(b)))

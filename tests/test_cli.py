@@ -146,6 +146,29 @@ def test_readme_fsk_stdout(cli, oracle, fsk, nofuse):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stride", [1024, 512])
+def test_windows_larger_than_the_lds_tile_print_the_reference_bytes(cli, oracle, tmp_path, stride):
+    """`lowpass -decimate 32 -power 100 ... sparkfft -width 1024`: 32 968 source samples per window, more than one workgroup's LDS holds.
+    stride == width runs as the library's two-stage plan; overlapping windows (stride 512) have no fused plan and the driver pulls them
+    through the iterator chain (read_exact_at per window, as src/fft.rs:30 does) — both print the oracle's bytes."""
+    n = 6 * 1024 * 32 + 900
+    t = np.arange(n)
+    rng = np.random.default_rng(9)
+    z = 0.2 * np.exp(2j * np.pi * 0.0004 * t) * np.sign(np.sin(t * 0.0003) + 1e-9) + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    data = np.stack([z.real, z.imag], 1).astype(np.float32).tobytes()
+    f = tmp_path / "big-window.sr21M.cf32"
+    f.write_bytes(data)
+    ch = oracle.Chain.from_bytes(data, oracle.FMT_CF32, 21_000_000).lowpass(150000, 32, 200)
+    norms, _ = ch.spark_fft(1024, stride)
+    rmin, rmax = float(np.percentile(norms, 20)), float(np.percentile(norms, 99))
+    r = run(cli, "from", str(f), "lowpass", "-power", "100", "-decimate", "32", "150000", "sparkfft", "-width", "1024", "-stride", str(stride),
+            "-range", f"{rmin!r}:{rmax!r}")
+    assert r.returncode == 0, r.stderr
+    want = ch.spark_text(1024, stride, (np.float32(rmin), np.float32(rmax)))
+    assert r.stdout == want
+
+
+@pytest.mark.gpu
 def test_bucket_and_default_flags(cli, oracle, fsk):
     f = os.path.join(GOLDEN, "fsk-example-head65536.sr21M.cf32")
     r = run(cli, "from", f, "shift", "280000", "lowpass", "2000000", "bucket", "-by", "freq", "2")

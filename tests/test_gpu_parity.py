@@ -371,6 +371,74 @@ def test_glyph_and_bucket_epilogues(engine, oracle, fsk):
         assert np.array_equal(got2, ref2) and 0.2 < ref2.mean() < 0.8
 
 
+@pytest.mark.parametrize("fmt,D,T,W,shift", [(0, 32, 200, 1024, 280000),     # lowpass -decimate 32 -power 100 ... sparkfft -width 1024: 32 968 source samples per window
+                                                 (0, 64, 40, 512, None),          # lowpass -decimate 64 ... -width 512: 32 808
+                                                 (1, 128, 400, 256, 280000),      # cs8, -decimate 128: 33 168 per window, 16 584-sample sub-blocks do not fit either
+                                                 (3, 16, 64, 4096, -1_234_567)])  # cs16, a 4096-point window
+def test_windows_larger_than_the_lds_tile(engine, oracle, fmt, D, T, W, shift):
+    """LowPass::read_at allocates whatever buf.len() * D + T asks for (src/filter.rs:68-69): a window whose FIR input does not fit one
+    workgroup's LDS (W D + T > ~19 000 samples) returned QD_ERR_UNSUPPORTED until round 4.  With stride == width it now runs as a
+    two-stage plan — the chain into read_at blocks of W decimated samples (the write sink's kernels: per-block truncation is the
+    sink's per-window truncation, src/filter.rs:68-83), then W-point windows over that stream — through the same qd_plan_run: norms,
+    glyph codes and bucket digits against the oracle, window sub-ranges, the device path."""
+    import torch
+    bps = {0: 8, 1: 2, 2: 2, 3: 4}[fmt]
+    nwin = 7
+    n = nwin * W * D + T + 3 * D + 5
+    rng = np.random.default_rng(W + D)
+    if fmt == 0:
+        t = np.arange(n)
+        z = 0.2 * np.exp(2j * np.pi * (0.0004 * t)) * np.sign(np.sin(t * 0.0003) + 1e-9) + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        data = np.stack([z.real, z.imag], 1).astype(np.float32).tobytes()
+    elif fmt == 3:
+        data = rng.integers(-3000, 3000, size=(n, 2), dtype=np.int64).astype(np.int16).tobytes()
+    else:
+        data = rng.integers(0, 256, size=(n, 2), dtype=np.int64).astype(np.uint8).tobytes()
+    sr, fc = 21_000_000, 150_000
+    ch = oracle.Chain.from_bytes(data, fmt, sr)
+    if shift is not None:
+        ch = ch.shift(shift)
+    ch = ch.lowpass(fc, D, T)
+    ref, _ = ch.spark_fft(W, W)
+    kw = dict(shift_hz=shift, lowpass=(fc, D, T), width=W, stride=W)
+    p = engine.Plan(fmt, sr, n, **kw)
+    assert p.n_windows == ref.shape[0] == oracle.lib().qo_spark_window_count(ch.len(), W, W)
+    got = p.run_host(data)
+    if shift is None:
+        assert_norms_close(ref, got, f"two-stage fmt={fmt} W={W} D={D}", min_exact=1.0, max_ulp=0.0)
+    else:
+        assert_norms_close(ref, got, f"two-stage fmt={fmt} W={W} D={D}")
+    # a window sub-range from a slab that starts inside the stream, host and device buffers
+    w0, cnt = 2, p.n_windows - 3
+    first, count = p.src_range(w0, cnt)
+    sub = p.run_host(data[first * bps:(first + count) * bps], w0, cnt, src_first=first)
+    assert np.array_equal(sub.view(np.uint32), got[w0:w0 + cnt].view(np.uint32))
+    src = torch.frombuffer(bytearray(data[first * bps:(first + count) * bps]), dtype=torch.uint8).cuda()
+    out = torch.empty(cnt, W, dtype=torch.float32, device="cuda")
+    for _ in range(2):                                     # twice: the carrier buffer is reused
+        p.run_device(src, out, w0, cnt, src_first=first, src_count=count)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), got[w0:w0 + cnt].view(np.uint32))
+    # the other sinks
+    rmin, rmax = float(np.percentile(ref, 20)), float(np.percentile(ref, 99))
+    _, ref_codes = ch.spark_fft(W, W, (rmin, rmax))
+    codes = engine.Plan(fmt, sr, n, epilogue=engine.EPI_GLYPH_U8, rng=(rmin, rmax), **kw).run_host(data)
+    assert_codes_edge_aware(ref_codes, codes, ref, rmin, rmax, f"two-stage glyph W={W}")
+    pb = engine.Plan(fmt, sr, n, epilogue=engine.EPI_BUCKET2_U8, **kw)
+    vals, ref_vals = pb.run_host(data), ch.freq_levels(W, W)
+    assert pb.n_windows == ref_vals.size
+    dv = np.flatnonzero(vals != ref_vals)
+    halves = np.stack([ref[:vals.size].astype(np.float64)[:, :W // 2].sum(axis=1), ref[:vals.size].astype(np.float64)[:, W // 2:].sum(axis=1)], axis=1)
+    for w in dv:
+        a, b = float(halves[w, 0]), float(halves[w, 1])
+        assert abs(a - b) <= 8 * float(np.spacing(np.float32(max(a, b)))), (int(w), a, b)
+    # overlapping windows of that size have no plan (the CLI pulls them through the iterator chain instead)
+    with pytest.raises(engine.QuadrsError) as ei:
+        engine.Plan(fmt, sr, n, shift_hz=shift, lowpass=(fc, D, T), width=W, stride=W // 2)
+    from quadrs_amd import _ffi
+    assert ei.value.code == _ffi.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("fmt,D,T,B,shift", [(0, 4, 40, 4096, None), (0, 8, 40, 4096, 280000), (1, 16, 400, 4096, 280000),
                                               (0, 3, 10, 64, None), (0, 32, 200, 1024, -100000)])
 def test_fused_write_blocks(engine, oracle, fmt, D, T, B, shift):
