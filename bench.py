@@ -45,6 +45,11 @@ WORKLOADS = {
     # BASELINE.json configs[4]: the cfg3 chain on a cf32 stream sharded over the node, 16 GiB per GPU (128 GiB at 8 GPUs)
     "cfg5": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=280000, lp=(200_000, 32, 400), W=64, S=16,
                  desc="{size} cf32 per GPU: shift 280000 -> lowpass -power 200 -decimate 32 200000 -> sparkfft -width 64 -stride 16 (configs[4])"),
+    # chains WITHOUT a lowpass (README example 1 / configs[0]'s chain at scale; the default run reports them under "no_lowpass"): here as
+    # workloads so that the profile scripts can put rocprofv3 around them
+    "nolp": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=None, lp=None, W=128, S=128, desc="{size} cf32: sparkfft -width 128 (no shift, no lowpass)"),
+    "nolp_shift": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=280000, lp=None, W=128, S=128, desc="{size} cf32: shift 280000 -> sparkfft -width 128 (no lowpass)"),
+    "nolp1024": dict(fmt=0, n=1 << 31, sr=21_000_000, shift=None, lp=None, W=1024, S=1024, desc="{size} cf32: sparkfft -width 1024 (no shift, no lowpass)"),
 }
 
 
@@ -74,7 +79,7 @@ def valu_ops_per_sample(cfg, nco_order):
     / 12 (second order) f64 ops + 2 f64->f32 converts, complex multiply 3 packed ops; FFT ~5 W log2 W flops per window; |X| per
     bin: the short exact form (see below); unpack per sample (two components):
     8-bit ~10 f32 ops (convert, bias, multiply by the reciprocal, residual, correction), cs16 12."""
-    fc, D, T = cfg["lp"]
+    fc, D, T = cfg["lp"] if cfg["lp"] else (0, 1, 0)
     W, S = cfg["W"], cfg["S"]
     f32 = 5.0 * W * math.log2(W) / (S * D)
     pk = 2.0 * T / D
@@ -799,9 +804,9 @@ def main():
             "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {workload_desc(cfg)}", "samples_per_gpu": cfg["n"], "taps": cfg["lp"][2],
-                       "decimate": cfg["lp"][1], "width": cfg["W"], "stride": cfg["S"],
-                       "parallelism": f"window-range shards x{world}, halo {(cfg['W'] - cfg['S']) * cfg['lp'][1] + cfg['lp'][2]} samples",
+            "config": {"workload": f"{args.workload}: {workload_desc(cfg)}", "samples_per_gpu": cfg["n"], "taps": cfg["lp"][2] if cfg["lp"] else 0,
+                       "decimate": cfg["lp"][1] if cfg["lp"] else 1, "width": cfg["W"], "stride": cfg["S"],
+                       "parallelism": f"window-range shards x{world}, halo {(cfg['W'] - cfg['S']) * (cfg['lp'][1] if cfg['lp'] else 1) + (cfg['lp'][2] if cfg['lp'] else 0)} samples",
                        "outputs_finite": main_res["outputs_finite"], "kernel_kind": main_res["kernel_kind"], "kernel_flags": main_res["kernel_flags"],
                        "tile_windows": main_res["tile_windows"], "threads": main_res["threads"],
                        # 1: first-order NCO correction, 2: second-order (streams whose phase n*|ratio| passes 2^28 rad: every multi-rank run of

@@ -3278,9 +3278,20 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
     if constexpr (HAS_SHIFT) { for (uint32_t i = tid; i < kSparkRow; i += kThreads) jt[i] = P.jtab[i]; }
     __syncthreads();                                                       // the only workgroup barrier
 
+    // LDS swizzle of the transform buffer.  The first layer (cols = base) reads point chunk * 4 base + k * base + i: the 32 lanes of a
+    // half-wave span i (log_base bits) and the low 5 - log_base bits of `chunk`, which lie above bit 5 of the index — every lane group
+    // of 8 (16) hits the same banks, a 4-way (2-way) conflict on all of that layer's reads and writes (rocprofv3, W = 128:
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 54 %).  XOR those chunk bits into the index bits just above i: a bijection that keeps
+    // runs of `base` points contiguous (the base pass still writes 16-byte pieces) and leaves the wider layers conflict-free.
+    // The bucket sink reads the buffer linearly afterwards: no swizzle there.
+    constexpr bool kSwz = EPI != 2;
+    auto sw = [](uint32_t p) -> uint32_t {
+        constexpr uint32_t lb = GeoT::log_base, nb = 5 - lb;
+        return kSwz ? p ^ (((p >> (lb + 2)) & ((1u << nb) - 1u)) << lb) : p;
+    };
     const uint32_t g = lane / LPW, xp = lane % LPW;                        // this lane's window of the tile and its column pair (2 xp, 2 xp + 1)
     // LDS positions of the lane's two base butterflies' outputs (contiguous runs of `base` points)
-    const uint32_t p0 = g * W + (rev4(2 * xp, layers) << GeoT::log_base), p1 = g * W + (rev4(2 * xp + 1, layers) << GeoT::log_base);
+    const uint32_t p0 = sw(g * W + (rev4(2 * xp, layers) << GeoT::log_base)), p1 = sw(g * W + (rev4(2 * xp + 1, layers) << GeoT::log_base));
     const uint64_t n_tiles = (P.n_windows + GW - 1) / GW;
     SparkWalk walk(n_tiles, wave);
     uint64_t tile = walk.first;
@@ -3387,12 +3398,12 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
 #pragma unroll
             for (uint32_t k0 = 0; k0 < NBF; k0 += KB) {
                 float2 s[KB][4];
-                float2 *dp[KB];
+                uint32_t dp[KB][4];
 #pragma unroll
                 for (uint32_t kk = 0; kk < KB; ++kk) {
                     const uint32_t t = lo + 64 * (k0 + kk), chunk = t >> log_cols, i = t & (cols - 1);
-                    dp[kk] = fbw + (size_t)chunk * 4 * cols + i;
-                    s[kk][0] = dp[kk][0]; s[kk][1] = dp[kk][cols]; s[kk][2] = dp[kk][2 * cols]; s[kk][3] = dp[kk][3 * cols];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) { dp[kk][q] = sw(chunk * 4 * cols + i + q * cols); s[kk][q] = fbw[dp[kk][q]]; }
                 }
 #pragma unroll
                 for (uint32_t kk = 0; kk < KB; ++kk) {
@@ -3404,7 +3415,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
                 }
                 if (!last || EPI == 2) {
 #pragma unroll
-                    for (uint32_t kk = 0; kk < KB; ++kk) { dp[kk][0] = s[kk][0]; dp[kk][cols] = s[kk][1]; dp[kk][2 * cols] = s[kk][2]; dp[kk][3 * cols] = s[kk][3]; }
+                    for (uint32_t kk = 0; kk < KB; ++kk)
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q) fbw[dp[kk][q]] = s[kk][q];
                 } else {
                     // cols == W / 4: butterfly t of the tile is butterfly i of window t >> log_cols; result k is bin i + k W/4, output (bin + W/2) mod W.
                     // The four |X| of a butterfly take the short form together and test ONE flag for the IEEE form (3e-5 of the bins).

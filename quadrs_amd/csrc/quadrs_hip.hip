@@ -283,9 +283,14 @@ FftLayout fft_layout(uint64_t W) {
 #endif
 
 // ---- generic kernels (DynGeo): every shape; chunked prefetch of 4 rows; aligned / unaligned slab
+// Register budget of the runtime-geometry kernels: four waves per SIMD (128 VGPRs) without a shift; with one, the NCO's f64 temporaries
+// and lane constants on top of the prefetch and the five base-butterfly paths spill at that budget (round 3: up to 74 VGPRs and 108
+// bytes of scratch per lane on the cs16 / second-order instantiations, reloaded behind vmcnt(0) drains in the tile loop), so those are
+// budgeted for three waves (168 VGPRs; plan_init caps their workgroups per CU at three).  tests/test_abi_cpu.py audits every one.
+constexpr int dyn_lb(int nco) { return nco == 0 ? 4 : 3; }
 template <int F, int NCO, bool FI>
 chain_fn pick_dyn(bool aligned) {
-    return aligned ? k_chain<F, NCO, DynGeo, FI, 4, false, true, 4> : k_chain<F, NCO, DynGeo, FI, 4, false, false, 4>;
+    return aligned ? k_chain<F, NCO, DynGeo, FI, 4, false, true, dyn_lb(NCO)> : k_chain<F, NCO, DynGeo, FI, 4, false, false, dyn_lb(NCO)>;
 }
 
 template <int F>
@@ -308,17 +313,16 @@ chain_fn pick_generic(int fmt, int nco, bool fir, bool aligned) {
 template <int F, int TS>
 chain_fn pick_spark_ts(int nco) {
     constexpr int NCH = TS / (int)SparkTraits<F>::CH;
-    constexpr int LBS = TS == 512 ? 3 : 2;      // chains with a shift: register budget of three (two) waves per SIMD, see spark_lb
-    switch (nco) {
+    switch (nco) {                              // chains with a shift: register budget of three (two) waves per SIMD, see spark_lb
     case 0: return k_spark<F, 0, DynGeo, NCH, 4>;
-    case 1: return k_spark<F, 1, DynGeo, NCH, LBS>;
-    default: return k_spark<F, 2, DynGeo, NCH, LBS>;
+    case 1: return k_spark<F, 1, DynGeo, NCH, (TS == 512 ? 3 : 2)>;
+    default: return k_spark<F, 2, DynGeo, NCH, 2>;
     }
 }
 // waves per SIMD the built-in kernel is register-budgeted for (= workgroups per CU): without a shift 128 VGPRs hold everything;
 // with one, the lane constants of the row quarters (16 doubles), the NCO's f64 temporaries and the next tile's prefetch beside the
 // sixteen-point butterflies need ~150 (tiles of 512 samples) / ~190 (1024): budgeted at 4 they spill 9-85 registers to scratch
-int spark_lb(uint32_t ts, int nco) { return nco == 0 ? 4 : (ts == 512 ? 3 : 2); }
+int spark_lb(uint32_t ts, int nco) { return nco == 0 ? 4 : (nco == 1 && ts == 512 ? 3 : 2); }
 // tile sizes of the built-in (runtime-width) kernels: 1024 samples per wave, which fills the lanes of the sixteen-point base
 // butterflies too; chains WITH a shift take 512 up to W = 512 — their lane constants (16 doubles) and the NCO's f64 temporaries on top
 // of 1024 samples of prefetch do not fit 128 registers (61-85 spilled), with 512 they do
@@ -1283,9 +1287,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             // the same kernel with the width as a compile-time constant (butterfly loops unroll, one base butterfly instead of five,
             // index arithmetic folds): cached builds always, a new one for streams of 1 GiB and more.  Falls back to the built-in
             // runtime-width kernel — same tiling, same bytes.
-            JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, spark_lb(p->spark_ts, p->nco), kThreads,
+            // (with the width a constant one base butterfly is compiled instead of five: a shift fits three waves per SIMD at either tile size)
+            const int lbj = p->nco == 0 ? 4 : 3;
+            JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, lbj, kThreads,
                      p->W, p->S, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull};
             p->jit_fn = jit_chain_kernel(k, &p->jit_note, may_compile);
+            if (p->jit_fn) p->spark_lb = lbj;
         }
         const bool want = !heavy && !p->spark && (tuned || (!p->fixed && jit_ok && (!write_sink || auto_variant)));
         if (want) {
@@ -1339,6 +1346,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     p->wg_per_cu = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
     if (p->fixed) { int by_regs = p->fixed->lb * 256 / p->fixed->nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (p->spark) { const int by_regs = p->spark_lb; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
+    if (!p->fixed && !p->jit_fn && !p->spark) { const int by_regs = dyn_lb(p->nco); if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }      // the generic kernels' own budget
     if (p->launch_nt > kThreads) { int by_threads = 2048 / p->launch_nt; if (p->wg_per_cu > by_threads) p->wg_per_cu = by_threads; }
     if (tuned || heavy || auto_variant) { int by_regs = (jit_lb * 4 * 64) / p->launch_nt; if (by_regs < 1) by_regs = 1; if (p->wg_per_cu > by_regs) p->wg_per_cu = by_regs; }
     if (tuned && tune[7] && (int)tune[7] < p->wg_per_cu) p->wg_per_cu = (int)tune[7];

@@ -9,7 +9,7 @@ if "--workload" in args:
 res = {"tag": tag, "workload": workload, "bench_args": args}
 ks = glob.glob(f"{out}/kt/*/*kernel_stats.csv")
 rows = list(csv.DictReader(open(ks[0])))
-chain = [r for r in rows if "k_chain" in r["Name"]]
+chain = [r for r in rows if "k_chain" in r["Name"] or "k_spark" in r["Name"]]
 # a run may launch a second, tiny chain kernel for windows at an unaligned slab end: the profiled kernel is the one with the most time
 chain.sort(key=lambda r: -float(r["AverageNs"]) * float(r["Calls"]))
 main_name = chain[0]["Name"] if chain else ""

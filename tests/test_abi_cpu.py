@@ -134,5 +134,13 @@ def test_builtin_kernels_do_not_spill(engine):
     for k, v in fixed.items():
         short = "Lj128ELj128E" in k
         assert v.get("SGPRs Spill", 0) <= (24 if short else 160), (k, v)
-    generic = {k: v for k, v in res.items() if "k_chain" in k and "DynGeo" in k}
-    assert generic and all(v.get("ScratchSize", 0) <= 256 for v in generic.values()), {k: v for k, v in generic.items() if v.get("ScratchSize", 0) > 256}
+    # round 4: EVERY kernel of the library — the runtime-geometry (DynGeo) chain kernels and the wave-local kernels included — without
+    # scratch.  The generic kernels serve every stream below 1 GiB that has no cached plan-time build (both README examples); with a shift
+    # they are budgeted for three waves per SIMD instead of spilling up to 74 VGPRs at four (round 3).  SGPR spills (lanes of a VGPR, no
+    # memory) are bounded at today's figures: the generic kernels keep ~50 runtime geometry values uniform.
+    generic = {k: v for k, v in res.items() if "DynGeo" in k}
+    assert len(generic) >= 60, len(generic)
+    bad = {k: v for k, v in res.items() if v.get("ScratchSize", 0) > 0 or v.get("VGPRs Spill", 0) > 0}
+    bad = {k: v for k, v in bad.items() if not ("FixedGeo" in k and v.get("VGPRs Spill", 0) <= 2 and v.get("ScratchSize", 0) <= 16)}       # (the bound above)
+    assert not bad, bad
+    assert all(v.get("SGPRs Spill", 0) <= 160 for v in generic.values()), {k: v for k, v in generic.items() if v.get("SGPRs Spill", 0) > 160}
