@@ -136,7 +136,13 @@ def lib():
             "qd_host_unregister": (i32, [vp]),
         }
         for name, (res, args) in sig.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                # only a diagnostic library named by QD_LIB_PATH (an older build kept for a before / after timing) may lack an entry point
+                if os.environ.get("QD_LIB_PATH") and name in ("qd_plan_kernel_name",):
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

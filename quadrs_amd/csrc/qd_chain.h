@@ -1409,7 +1409,9 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
     // Per-lane NCO constants: 3 doubles per sample slot.  Kernels whose FIR is register-hungry (register-tiled
     // long filters) re-derive them at the top of every tile instead of keeping 8*SPL VGPRs live across the FIR
     // (the table is L2-resident; a tile of such a shape costs tens of thousands of cycles).
-    constexpr bool kReloadLane = HAS_SHIFT && GeoT::kFixed && GeoT::kFirTile > 1;
+    // ... and so do the runtime-geometry kernels (round 4): with the five base-butterfly paths and the generic FIR loops they sit at the
+    // 128-VGPR budget of four waves per SIMD, and the lane constants (6 SPL registers) were what spilled to scratch
+    constexpr bool kReloadLane = HAS_SHIFT && ((GeoT::kFixed && GeoT::kFirTile > 1) || !GeoT::kFixed);
     constexpr bool kFastP1 = fast_p1_ok<FMT, NT, GeoT>(RCH, WHOLE, ALIGNED);
     constexpr bool kHalf = GeoT::kHalfTile;                 // two passes per window (FixedGeo::kHalfTile); `half` = the pass this iteration runs
     static_assert(!kHalf || (kFastP1 && defer_fft_ok<GeoT, HAS_FIR>((uint32_t)NT)), "half-window tiles: row-aligned phase 1 and the deferred FFT");

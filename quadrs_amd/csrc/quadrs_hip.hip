@@ -283,11 +283,13 @@ FftLayout fft_layout(uint64_t W) {
 #endif
 
 // ---- generic kernels (DynGeo): every shape; chunked prefetch of 4 rows; aligned / unaligned slab
-// Register budget of the runtime-geometry kernels: four waves per SIMD (128 VGPRs) without a shift; with one, the NCO's f64 temporaries
-// and lane constants on top of the prefetch and the five base-butterfly paths spill at that budget (round 3: up to 74 VGPRs and 108
-// bytes of scratch per lane on the cs16 / second-order instantiations, reloaded behind vmcnt(0) drains in the tile loop), so those are
-// budgeted for three waves (168 VGPRs; plan_init caps their workgroups per CU at three).  tests/test_abi_cpu.py audits every one.
-constexpr int dyn_lb(int nco) { return nco == 0 ? 4 : 3; }
+// Register budget of the runtime-geometry kernels: four waves per SIMD (128 VGPRs).  Round 3's builds spilled there once a shift was in
+// the chain (up to 74 VGPRs / 108 bytes of scratch per lane on the cs16 and second-order instantiations, reloaded behind vmcnt(0)
+// drains in the tile loop).  Round 4: the lane constants are re-read from the (L2-resident) lane table at the top of every tile
+// instead of held across it (k_chain kReloadLane) — no scratch at four waves for the first-order NCO; the second-order kernels (streams
+// past 2^28 rad of phase, which get a plan-time build anyway) are budgeted for three.  Budgeting ALL shifted kernels for three waves
+// removed the scratch too but cost 6-18 % on 256 MiB streams (profiles/r04/generic_rate.log).  tests/test_abi_cpu.py audits every kernel.
+constexpr int dyn_lb(int nco) { return nco == 2 ? 3 : 4; }
 template <int F, int NCO, bool FI>
 chain_fn pick_dyn(bool aligned) {
     return aligned ? k_chain<F, NCO, DynGeo, FI, 4, false, true, dyn_lb(NCO)> : k_chain<F, NCO, DynGeo, FI, 4, false, false, dyn_lb(NCO)>;
