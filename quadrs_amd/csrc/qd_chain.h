@@ -1258,7 +1258,8 @@ __device__ __forceinline__ void wave_bucket_epilogue_fn(const ChainParams &P, co
 }
 
 template <class GeoT, uint32_t KB = 0 /* bucket epilogue: bins per lane the caller's buffer may hold (0: from the geometry) */,
-          int PART = 0 /* 0: the whole transform + epilogue; 1: the base butterflies only; 2: the radix-4 layers + epilogue of windows whose base pass is done */>
+          int PART = 0 /* 0: the whole transform + epilogue; 1: the base butterflies only; 2: the radix-4 layers + epilogue of windows whose base pass is done;
+                          3: base butterflies + layers, no epilogue (the caller has its own) */>
 __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const GeoT &geo, const float2 *twl, float2 *fbp, uint64_t pw0, uint32_t pg, uint32_t tid) {
     uint32_t lane = tid & 63u;
     asm volatile("" : "+v"(lane));            // opaque: per-lane LDS / output addresses are rebuilt per tile, not hoisted out of the tile loop and spilled
@@ -1313,6 +1314,7 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
         log_cols += 2;
     }
     wsync();
+    if constexpr (PART == 3) return;
     const uint64_t wrel = pw0 - P.out_window0;
     const uint32_t n_out_s = pg << geo.logW;
     if (P.epi == 2) {
@@ -3091,7 +3093,7 @@ template <int FMT> struct SparkTraits {
     static constexpr uint32_t SPL = FT::SPL, CH = 64u * SPL, RQ = kSparkRow / CH;       // chunk: one wave-wide load; RQ chunks per NCO row
 };
 
-template <int FMT, int NCO, class GeoT, int NCH, int LB>
+template <int FMT, int NCO, class GeoT, int NCH, int LB, int EPI = -1 /* plan-time builds: the plan's sink, compile-time (norms 0 / glyph 1: the lean epilogue below); -1: P.epi at run time */>
 __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
     using FT = FmtTraits<FMT>;
     using Vec = typename FT::Vec;
@@ -3172,6 +3174,20 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
         for (int c = 0; c < NCH; ++c) load_chunk(rsrc, c);
     }
     auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // The lean epilogue (plan-time builds with the sink known: see k_spark2 for the reasoning): no sink dispatch and no store branch in
+    // the tile loop — the output goes through a per-tile buffer descriptor that ends with the tile's last valid window —, four |X| per
+    // IEEE-path test, non-temporal stores, and the loop's entry edge issues as many (dropped) stores as a tile does so that the waits
+    // for the prefetched chunks stay counted instead of vmcnt(0).
+    constexpr bool kLean = GeoT::kFixed && (EPI == 0 || EPI == 1);
+    constexpr uint32_t NB = TS / 64;                                       // bins per lane and tile
+    if constexpr (kLean) {
+        const auto none = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out), 0, 0, 0x00020000);
+#pragma unroll
+        for (uint32_t q = 0; q < NB; ++q) {
+            if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(0u, none, (int)(lane * 4 + q * 256), 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, none, (int)(lane + q * 64), 0, 2);
+        }
+    }
     while (true) {
         const uint64_t tile_n = tile + n_waves;
         const auto rsrc_n = rsrc_of(tile_n < tile_end ? tile_n : tile);     // last tile of this wave: harmless re-loads
@@ -3224,6 +3240,34 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
             __builtin_amdgcn_sched_barrier(0);
         }
         wsync();
+        if constexpr (kLean) {
+            wave_fft_epilogue_fn<GeoT, 0, 3>(P, geo, twl, fbw, w0, G, tid);          // every window of the tile (rows past the slab read as zeros): compile-time trip counts
+            constexpr uint32_t OBW = EPI == 0 ? 4u * GeoT::W : GeoT::W;
+            const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * OBW, 0, g_cnt * OBW, 0x00020000);
+            uint32_t lo = lane;
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            for (uint32_t k0 = 0; k0 < NB; k0 += 4) {
+                float nm[4];
+                bool sl[4];
+                float2 xv[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) xv[q] = fbw[(lo + 64 * (k0 + q)) ^ (GeoT::W >> 1)];      // fftshift: bin (b + W/2) mod W of the same window
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) nm[q] = norm_fast(xv[q].x, xv[q].y, sl[q]);
+                if (__builtin_expect(sl[0] | sl[1] | sl[2] | sl[3], 0)) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) if (sl[q]) nm[q] = norm_ieee(xv[q].x, xv[q].y);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const uint32_t o = lo + 64 * (k0 + q);
+                    if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)(o * 4), 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep), orsrc, (int)o, 0, 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         wave_fft_epilogue_fn<GeoT, TS / 64>(P, geo, twl, fbw, w0, g_cnt, tid);
         wsync();                                                            // the next tile's samples overwrite what the epilogue read
         if (tile_n >= tile_end) break;

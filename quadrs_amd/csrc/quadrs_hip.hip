@@ -477,8 +477,8 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
                  k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.lb, k.epi);
     else
     if (k.flags & kGeoSpark)       // the wave-local kernel of chains without a lowpass: rch = chunks per tile
-        snprintf(name, sizeof name, "qd::k_spark<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
-                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb);
+        snprintf(name, sizeof name, "qd::k_spark<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d, %d>", k.fmt, k.nco, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.rch, k.lb, k.epi);
     else
     if ((k.flags & kGeoPipe3) && (k.flags & kGeoStream))       // ... its streaming form: contiguous runs of tiles, state carried in LDS rings
         snprintf(name, sizeof name, "qd::k_chain_pipe3s<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d, %d>", k.fmt, k.nco, k.W,
@@ -1292,7 +1292,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             // (with the width a constant one base butterfly is compiled instead of five: a shift fits three waves per SIMD at either tile size)
             const int lbj = p->nco == 0 ? 4 : 3;
             JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, lbj, kThreads,
-                     p->W, p->S, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull};
+                     p->W, p->S, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull, d.epilogue};
             p->jit_fn = jit_chain_kernel(k, &p->jit_note, may_compile);
             if (p->jit_fn) p->spark_lb = lbj;
         }
