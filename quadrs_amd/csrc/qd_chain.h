@@ -3331,9 +3331,25 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
     // runs of `base` points contiguous (the base pass still writes 16-byte pieces) and leaves the wider layers conflict-free.
     // The bucket sink reads the buffer linearly afterwards: no swizzle there.
     constexpr bool kSwz = EPI != 2;
-    auto sw = [](uint32_t p) -> uint32_t {
+    // ... and a second swizzle for the base pass's WRITES.  A lane stores its butterfly's `base` outputs as 16-byte pieces of one
+    // contiguous run; piece q of every lane goes out in the same instruction, 8 lanes to a group, and a group is conflict-free only if
+    // its 8 pieces fall into the 8 different 16-byte slots of the 128 bytes the banks span.  With runs of 64 (128) bytes the slot is
+    // (run & 1) * 4 + q (just q): 2 (1) distinct slots, a 4-way (8-way) conflict on every store of the pass.  So piece q of run r is
+    // kept at piece position q ^ f(r), f made of the run-index bits in which the 8 lanes of a group differ (x = 2 xp + u: x bit 1 is
+    // run bit 2 L - 1, x bits 2-3 are run bits 2 L - 4, 2 L - 3; L = layers): the layers read element (r, y) at the same place, whole
+    // runs stay whole, the first swizzle works on higher index bits.
+    auto piece_f = [](uint32_t r) -> uint32_t {
+        constexpr uint32_t L2 = 2 * layers;
+        // (measured, 16 GiB cf32: base 16 — W = 1024 6.45 -> 5.72 ms, W = 256 with a shift 6.25 -> 5.90; base 8 — W = 128 4.74 -> 4.81: its 4-way
+        // conflict costs less than the index arithmetic, so eight-point runs keep their pieces in order)
+        if constexpr (base == 8) return 0u;
+        else return ((r >> (L2 - 1)) & 1u) | (((r >> (L2 - 4)) & 3u) << 1);
+    };
+    auto sw = [&](uint32_t p) -> uint32_t {
         constexpr uint32_t lb = GeoT::log_base, nb = 5 - lb;
-        return kSwz ? p ^ (((p >> (lb + 2)) & ((1u << nb) - 1u)) << lb) : p;
+        if constexpr (!kSwz) return p;
+        const uint32_t r = (p >> lb) & (width - 1);                        // the run (base butterfly) the element belongs to, inside its window
+        return (p ^ (((p >> (lb + 2)) & ((1u << nb) - 1u)) << lb)) ^ (piece_f(r) << 1);
     };
     const uint32_t g = lane / LPW, xp = lane % LPW;                        // this lane's window of the tile and its column pair (2 xp, 2 xp + 1)
     // LDS positions of the lane's two base butterflies' outputs (contiguous runs of `base` points)
@@ -3415,9 +3431,13 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
 #if !(defined(QD_SPARK_ABL) && (QD_SPARK_ABL & 8))
             if constexpr (base == 16) bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2); else bf8(v, P.root2);
 #endif
-            float2 *d = fbw + (u == 0 ? p0 : p1);
+            const uint32_t pb = u == 0 ? p0 : p1;                          // swizzled position of the run's piece 0 ... of ITS piece position f: p0 / p1 are sw(run start)
 #pragma unroll
-            for (uint32_t y = 0; y < base; ++y) d[y] = v[y];
+            for (uint32_t q = 0; q < base / 2; ++q) {
+                // piece q (outputs 2 q, 2 q + 1) sits at piece position q ^ f: sw(run start) already has position f in its piece bits, so XOR q in
+                float2 *d = fbw + (pb ^ (kSwz ? (q << 1) : 0u)) + (kSwz ? 0u : 2 * q);
+                d[0] = v[2 * q]; d[1] = v[2 * q + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);                              // one column at a time (registers)
         }
         __builtin_amdgcn_sched_barrier(0);                                  // the rows are consumed: their registers take the next tile's rows
