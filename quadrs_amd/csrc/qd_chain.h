@@ -3110,10 +3110,15 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
     float2 *twl = reinterpret_cast<float2 *>(smem);                        // radix-4 layer twiddles (< W entries), shared by the four waves
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float2 *fbw = twl + (W < 16u ? 16u : W) + (size_t)wave * TS;           // this wave's transform buffer: TS complex samples
+    // Plan-time builds with a shift read the lane constants out of an LDS copy of the lane table (one ds_read_b128 per sample) instead of
+    // holding RQ * SPL (cos, sin) pairs — 32 registers — across the tile loop: that is what kept them at three waves per SIMD.
+    constexpr bool kLdsLane = HAS_SHIFT && GeoT::kFixed;
+    double2 *jt = reinterpret_cast<double2 *>(twl + (W < 16u ? 16u : W));
+    float2 *fbw = twl + (W < 16u ? 16u : W) + (kLdsLane ? 2u * kSparkRow : 0u) + (size_t)wave * TS;           // this wave's transform buffer: TS complex samples
     {
         const uint32_t n_tw = W - geo.base_len;
         for (uint32_t i = tid; i < n_tw; i += kThreads) twl[i] = P.tw[i];
+        if constexpr (kLdsLane) { for (uint32_t i = tid; i < kSparkRow; i += kThreads) jt[i] = P.jtab[i]; }
     }
     __syncthreads();                                                       // the only workgroup barrier
 
@@ -3133,13 +3138,15 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
     }
     // (cos, sin)(j * ratio) of the lane's sample slots in each row quarter; the slot index itself is kept for quarter 0 only — the
     // quarter's offset q * CH goes into the row's sample count instead (integers below 2^53: the same double whichever way they add up)
-    double2 lcs[HAS_SHIFT ? RQ * SPL : 1];
+    double2 lcs[HAS_SHIFT && !kLdsLane ? RQ * SPL : 1];
     double ljf[HAS_SHIFT ? SPL : 1];
     if constexpr (HAS_SHIFT) {
+        if constexpr (!kLdsLane) {
 #pragma unroll
-        for (uint32_t q = 0; q < RQ; ++q)
+            for (uint32_t q = 0; q < RQ; ++q)
 #pragma unroll
-            for (int u = 0; u < SPL; ++u) lcs[q * SPL + u] = P.jtab[q * CH + lane * SPL + (uint32_t)u];
+                for (int u = 0; u < SPL; ++u) lcs[q * SPL + u] = P.jtab[q * CH + lane * SPL + (uint32_t)u];
+        }
 #pragma unroll
         for (int u = 0; u < SPL; ++u) ljf[u] = (double)(lane * SPL + (uint32_t)u);
     }
@@ -3226,7 +3233,10 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
                 const int q = c % (int)RQ;
                 LaneRot lr[SPL];
 #pragma unroll
-                for (int u = 0; u < SPL; ++u) { lr[u].jf = ljf[u]; lr[u].c = lcs[q * SPL + u].x; lr[u].s = lcs[q * SPL + u].y; }
+                for (int u = 0; u < SPL; ++u) {
+                    const double2 cs = kLdsLane ? jt[(uint32_t)q * CH + lane * SPL + (uint32_t)u] : lcs[kLdsLane ? 0 : q * SPL + u];
+                    lr[u].jf = ljf[u]; lr[u].c = cs.x; lr[u].s = cs.y;
+                }
                 RowBase rbq = rb;
                 rbq.nf = rb.nf + (double)(q * (int)CH);
                 nco_mul_n<NCO == 2, SPL>(rbq, lr, P.ratio, m);

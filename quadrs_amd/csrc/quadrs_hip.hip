@@ -706,6 +706,7 @@ struct qd_plan {
     const FixedEntry *fixed = nullptr;
     uint32_t spark_ts = 0;               // ... its tile: samples per wave (512, 1024 or 2048)
     int spark_lb = 4;                    // ... waves per SIMD it is register-budgeted for (= workgroups per CU)
+    bool spark_jt_lds = false;           // ... plan-time k_spark with a shift: the lane table sits in LDS (8 KiB more)
     bool spark = false;                  // the wave-local kernel of chains without a lowpass (k_spark) is this plan's main kernel
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
@@ -1275,7 +1276,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     }
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
     if (p->spark) p->geo.lds_main = ((size_t)(p->W < 16 ? 16 : p->W) + 4 * (size_t)p->spark_ts) * 8 +     // twiddles | four waves' transform buffers (k_spark)
-                                    (((kflags & kGeoSparkReg) && p->has_shift) ? (size_t)kSparkRow * 16 : 0);   // k_spark2 with a shift: + the NCO lane table
+                                    ((((kflags & kGeoSparkReg) && p->has_shift) || p->spark_jt_lds) ? (size_t)kSparkRow * 16 : 0);   // plan-time builds with a shift: + the NCO lane table
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
@@ -1289,12 +1290,16 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             // the same kernel with the width as a compile-time constant (butterfly loops unroll, one base butterfly instead of five,
             // index arithmetic folds): cached builds always, a new one for streams of 1 GiB and more.  Falls back to the built-in
             // runtime-width kernel — same tiling, same bytes.
-            // (with the width a constant one base butterfly is compiled instead of five: a shift fits three waves per SIMD at either tile size)
-            const int lbj = p->nco == 0 ? 4 : 3;
+            // (with the width a constant one base butterfly is compiled instead of five, and with a shift the lane constants come out of an LDS
+            // copy of the lane table: 82-112 VGPRs, four waves per SIMD at either tile size)
+            const int lbj = 4;
             JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, lbj, kThreads,
                      p->W, p->S, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull, d.epilogue};
             p->jit_fn = jit_chain_kernel(k, &p->jit_note, may_compile);
-            if (p->jit_fn) p->spark_lb = lbj;
+            if (p->jit_fn) {
+                p->spark_lb = lbj; p->spark_jt_lds = p->has_shift;
+                if (p->spark_jt_lds) p->geo.lds_main += (size_t)kSparkRow * 16;       // (lds_main was sized above for the built-in kernel)
+            }
         }
         const bool want = !heavy && !p->spark && (tuned || (!p->fixed && jit_ok && (!write_sink || auto_variant)));
         if (want) {
