@@ -115,6 +115,9 @@ struct ChainParams {
     uint32_t lds_raw_elems;    // float2 capacity of the raw tile
     uint32_t lds_dyn;          // dynamic LDS bytes of this launch: the kernels with a layout of their own (three-stage kernels) check it
                                // against their compile-time need and do nothing if the host's restatement of the layout fell short
+    uint32_t out_row_stride;   // wave-local kernels (plan-time builds): output rows between consecutive windows of THIS launch (0 / 1: contiguous).
+                               // Overlapping windows without a lowpass run as W / S interleaved launches — launch phi takes the windows
+                               // phi, phi + R, phi + 2R ... (R = W / S), which lie side by side in the stream shifted by phi * S samples
 };
 
 // ---------------------------------------------------------------- geometry policies
@@ -3253,7 +3256,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
         if constexpr (kLean) {
             wave_fft_epilogue_fn<GeoT, 0, 3>(P, geo, twl, fbw, w0, G, tid);          // every window of the tile (rows past the slab read as zeros): compile-time trip counts
             constexpr uint32_t OBW = EPI == 0 ? 4u * GeoT::W : GeoT::W;
-            const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * OBW, 0, g_cnt * OBW, 0x00020000);
+            const uint32_t RS = P.out_row_stride ? P.out_row_stride : 1u;      // rows between this launch's windows (interleaved launches of overlapping windows)
+            const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * RS * OBW, 0,
+                                                                 g_cnt ? ((g_cnt - 1) * RS + 1) * OBW : 0u, 0x00020000);
             uint32_t lo = lane;
             asm volatile("" : "+v"(lo));
 #pragma unroll
@@ -3272,8 +3277,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) {
                     const uint32_t o = lo + 64 * (k0 + q);
-                    if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)(o * 4), 0, 2);
-                    else __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep), orsrc, (int)o, 0, 2);
+                    const uint32_t oo = (((o >> GeoT::logW) * RS) << GeoT::logW) + (o & (GeoT::W - 1));      // window o / W lands RS rows apart
+                    if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)(oo * 4), 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep), orsrc, (int)oo, 0, 2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -3402,7 +3408,9 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
         const uint64_t w0 = P.first_window + tile * GW, left_w = P.first_window + P.n_windows - w0;
         const uint32_t g_cnt = left_w < GW ? (uint32_t)left_w : GW;
         constexpr uint32_t OBW = EPI == 0 ? 4u * W : W;                     // output bytes per window (norms f32 / glyph u8)
-        const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * OBW, 0, g_cnt * OBW, 0x00020000);
+        const uint32_t RS = P.out_row_stride ? P.out_row_stride : 1u;      // rows between this launch's windows (interleaved launches of overlapping windows)
+        const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * RS * OBW, 0,
+                                                             g_cnt ? ((g_cnt - 1) * RS + 1) * OBW : 0u, 0x00020000);
         // ---- NCO row bases of this lane: the tile's rows are wave-uniform (scalar loads), a lane needs the one(s) its window lies in
         RowBase rbl[W > kSparkRow ? W / kSparkRow : 1];
         if constexpr (HAS_SHIFT) {
@@ -3523,7 +3531,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
                         // issues the same number of vector-memory operations and the waits for the prefetched rows stay COUNTED
                         // (vmcnt retires in order: a conditional store between the row loads and their use forces vmcnt(0), i.e. a
                         // wait for the tile's own stores to land).  Non-temporal: the output is written once and not read here.
-                        const uint32_t ob = (gw << logW) + i;               // element offset inside the tile's output
+                        const uint32_t ob = ((gw * RS) << logW) + i;        // element offset inside the tile's output
                         if constexpr (EPI == 0) {
 #pragma unroll
                             for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)((ob + q * cols) * 4), 0, 2);

@@ -707,6 +707,7 @@ struct qd_plan {
     uint32_t spark_ts = 0;               // ... its tile: samples per wave (512, 1024 or 2048)
     int spark_lb = 4;                    // ... waves per SIMD it is register-budgeted for (= workgroups per CU)
     bool spark_jt_lds = false;           // ... plan-time k_spark with a shift: the lane table sits in LDS (8 KiB more)
+    uint32_t spark_R = 0;                // ... overlapping windows (stride divides width, no shift): W / S interleaved launches of side-by-side windows; 0: none
     bool spark = false;                  // the wave-local kernel of chains without a lowpass (k_spark) is this plan's main kernel
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
@@ -786,6 +787,54 @@ void free_rowtab(RowTab *t) {
     *t = RowTab{};
 }
 
+// Overlapping windows without a lowpass or a shift, stride S dividing the width (qd_plan::spark_R = W / S): launch phi covers the windows
+// w = phi (mod R) of the range — side by side in the stream that starts phi * S samples later — and writes every R-th output row.
+// (Running the R launches over one 8 ... 128 MiB stretch of the stream after the other, so that the re-reads hit the memory-side cache,
+// was measured and is slower at every size: profiles/r04/phase_chunk.log.)
+int launch_spark_phases(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_first, uint64_t src_count, uint64_t first_window,
+                        uint64_t n_windows, uint64_t out_window0, void *out_d, hipStream_t st) {
+    const int bps = bps_of(p->d.format);
+    const uint64_t R = p->spark_R, W = p->W, S = p->S, obw = out_bytes_per_window(p);
+    if (tabs->launched) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));
+    ChainParams P{};
+    P.W = p->W; P.logW = p->logW; P.S = p->W; P.D = 1; P.T = 0; P.G = p->geo.G; P.Dp = 1;
+    P.dshift = 0; P.base_len = p->fft.base_len; P.log_base = p->fft.log_base; P.layers = p->fft.layers;
+    P.epi = (uint32_t)p->d.epilogue;
+    P.rmin = p->d.has_range ? p->d.range_min : 0.08f; P.rmax = p->d.has_range ? p->d.range_max : 1.0f;
+    P.gstep = (P.rmax - P.rmin) / 7.0f;
+    P.root2 = (float)std::sqrt(0.5);
+    P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
+    P.tw = p->tw_d; P.blk_len = p->W; P.lds_dyn = (uint32_t)p->geo.lds_main;
+    P.out_row_stride = (uint32_t)R;
+    if (p->timing) {
+        if (!p->ev_made) { HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1)); p->ev_made = true; }
+        HIPCHK(hipEventRecord(p->ev0, st));
+    }
+    const uint64_t cap = (uint64_t)p->n_cu * p->wg_per_cu, last = first_window + n_windows - 1;
+    for (uint64_t phi = 0; phi < R; ++phi) {
+        if (last < phi) break;
+        const uint64_t k_lo = first_window > phi ? (first_window - phi + R - 1) / R : 0, k_hi = (last - phi) / R;
+        if (k_hi < k_lo) continue;
+        const uint64_t n_phi = k_hi - k_lo + 1, shift_samples = phi * S;
+        if (k_lo * W + shift_samples < src_first || (k_hi * W + shift_samples + W) > src_first + src_count)
+            return fail(QD_ERR_INVALID, "src slab [%llu,+%llu) does not cover the samples of windows [%llu,+%llu)", (unsigned long long)src_first,
+                        (unsigned long long)src_count, (unsigned long long)first_window, (unsigned long long)n_windows);
+        P.src = static_cast<const uint8_t *>(src_d) + shift_samples * bps;      // sample n of this launch is sample n + phi S of the stream
+        P.src_first = src_first; P.src_count = src_count - shift_samples;
+        P.first_window = k_lo; P.n_windows = n_phi; P.out_window0 = k_lo;
+        P.out = static_cast<uint8_t *>(out_d) + ((k_lo * R + phi) - out_window0) * obw;
+        const uint64_t n_tiles = (n_phi + P.G - 1) / P.G, wgs = (n_tiles + 3) / 4;
+        const uint32_t grid = (uint32_t)(wgs < cap ? wgs : cap);
+        void *args[] = {&P};
+        HIPCHK(hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, (unsigned)p->launch_nt, 1, 1, (unsigned)p->geo.lds_main, st, args, nullptr));
+    }
+    if (p->timing) { HIPCHK(hipEventRecord(p->ev1, st)); p->ev_recorded = true; }
+    if (!tabs->done) HIPCHK(hipEventCreateWithFlags(&tabs->done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(tabs->done, st));
+    tabs->last_stream = st; tabs->launched = true;
+    return QD_OK;
+}
+
 int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_first, uint64_t src_count, uint64_t first_window,
                  uint64_t n_windows, uint64_t out_window0, void *out_d, hipStream_t st) {
     if (n_windows == 0) return QD_OK;
@@ -798,6 +847,13 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
                     (unsigned long long)src_first, (unsigned long long)src_count, (unsigned long long)need0,
                     (unsigned long long)need1, (unsigned long long)first_window, (unsigned long long)n_windows);
     int rc = QD_OK;
+    bool phases_unaligned = false;
+    if (p->spark_R > 1) {
+        // interleaved launches of side-by-side windows; a slab that does not start on a load vector goes to the per-sample kernel as ever
+        if (p->jit_fn && !p->row_offsets_d && (reinterpret_cast<uintptr_t>(src_d) % (spl * bps)) == 0 && (src_first % spl) == 0)
+            return launch_spark_phases(p, tabs, src_d, src_first, src_count, first_window, n_windows, out_window0, out_d, st);
+        phases_unaligned = true;
+    }
     // see NcoTabs.  ALWAYS wait: a stream handle compared with the previous caller's may be a new stream at a recycled address (the old one
     // destroyed with its kernels still running); a wait on an event recorded in the same stream costs nothing
     if (tabs->launched) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));
@@ -855,7 +911,7 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     // row-aligned phase 1 with G S D (not S D) a multiple of the row: the launch's first window must sit on a row boundary too
     bool fast_misaligned = (p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
     // the wave-local kernel: tiles start on NCO rows when the chain shifts, on load vectors otherwise; irregular rows (take_fft) never run on it
-    if (p->spark) fast_misaligned = p->row_offsets_d != nullptr || ((first_window * p->W) % (p->has_shift ? (uint64_t)kSparkRow : (uint64_t)spl)) != 0;
+    if (p->spark) fast_misaligned = phases_unaligned || p->row_offsets_d != nullptr || ((first_window * p->W) % (p->has_shift ? (uint64_t)kSparkRow : (uint64_t)spl)) != 0;
     if (vec_ok && !fast_misaligned) {
         // windows [first_window, first_window + n_aligned): need-end rounded up to a vector fits in the slab
         const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
@@ -1049,6 +1105,13 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     const bool lut8 = d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8;
     // chains without a lowpass whose windows lie side by side: the wave-local kernel (k_spark), for every width it holds in a tile
     p->spark = !p->has_fir && p->S == p->W && p->W <= kSparkMaxW && d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC;
+    // ... and OVERLAPPING windows without a lowpass or a shift whose stride divides the width (`sparkfft -width 4 -stride 2`: README example 1,
+    // BASELINE configs[0]'s chain): the windows phi, phi + R, phi + 2R ... (R = W / S) lie side by side in the stream shifted by phi * S
+    // samples, so the chain is R launches of the same wave-local kernel, each writing every R-th output row.  Plan-time builds only (the
+    // row stride lives in their lean epilogue), norms and glyph sinks; everything else stays on k_chain.
+    if (!p->has_fir && !p->has_shift && p->S < p->W && p->W % p->S == 0 && p->W <= kSparkMaxW && p->W / p->S <= 32 &&
+        (d.epilogue == QD_EPI_NORMS_F32 || d.epilogue == QD_EPI_GLYPH_U8) && policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME &&
+        ((uint64_t)p->S * bps_of(d.format)) % 4 == 0 && p->W >= (uint32_t)spl_of(d.format)) { p->spark = true; p->spark_R = p->W / p->S; }
     uint32_t tune[8] = {0, 0, 1, 8, 4, 1, 1, 0};
     uint32_t hint_flags = 0;
     bool tuned = false;
@@ -1243,11 +1306,26 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         if (jit_ok && d.format == QD_FMT_CF32 && (p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024)) {
             // cf32, width 16 or 64 columns: the plan-time kernel that runs the base butterflies out of the row registers (k_spark2);
             // tile = 64 lanes x 2 columns x base rows.  Cached builds always, a new one for streams of 1 GiB and more.
+            // (the kernel's own geometry is windows side by side: S = W also where the plan's windows overlap, see spark_R)
             const uint32_t fbase = (ilog2(p->W) & 1) ? 8u : 16u, ts2 = 128u * fbase, g2 = ts2 / p->W;
             const int lb2 = p->has_shift ? (fbase == 8 ? 3 : 2) : (fbase == 8 ? 4 : 3);
-            JitKey k{d.format, p->nco, 0, 0, 1, lb2, kThreads, p->W, p->S, 1, 0, g2, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkReg, 0ull, d.epilogue};
+            JitKey k{d.format, p->nco, 0, 0, 1, lb2, kThreads, p->W, p->W, 1, 0, g2, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkReg, 0ull, d.epilogue};
             if (hipFunction_t f = jit_chain_kernel(k, &p->jit_note, may_compile)) {
                 p->jit_fn = f; p->spark_ts = ts2; G = g2; kflags |= kGeoSparkReg; p->spark_lb = lb2;
+            }
+        }
+        if (p->spark_R > 1 && !p->jit_fn) {
+            // interleaved launches need a plan-time build (k_spark with the sink as a template argument); none to be had: back to k_chain
+            const int lbj = 4;
+            JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, lbj, kThreads,
+                     p->W, p->W, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull, d.epilogue};
+            p->jit_fn = jit_ok ? jit_chain_kernel(k, &p->jit_note, may_compile) : nullptr;
+            if (p->jit_fn) p->spark_lb = lbj;
+            else {
+                p->spark = false; p->spark_R = 0; p->spark_ts = 0; kflags = 0; p->nt = kThreads; G = 1;
+                while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
+                while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
+                if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
             }
         }
     } else {
@@ -1294,7 +1372,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             // copy of the lane table: 82-112 VGPRs, four waves per SIMD at either tile size)
             const int lbj = 4;
             JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, lbj, kThreads,
-                     p->W, p->S, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull, d.epilogue};
+                     p->W, p->W, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull, d.epilogue};
             p->jit_fn = jit_chain_kernel(k, &p->jit_note, may_compile);
             if (p->jit_fn) {
                 p->spark_lb = lbj; p->spark_jt_lds = p->has_shift;
@@ -1511,7 +1589,7 @@ int qd_plan_create_ex(const qd_chain_desc *desc, const qd_plan_options *options,
     // sharded plans: the parent describes the whole stream; each shard gets a plan of its own on its device
     const uint32_t n_shards = opt.n_shards > 1 ? opt.n_shards : 1;
     const uint64_t step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D, rpw = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
-    const uint32_t tile_api = p->blk_len ? 1u : p->geo.G;        // API windows of the write sink are whole blocks
+    const uint32_t tile_api = (p->blk_len || p->spark_R > 1) ? 1u : p->geo.G;        // API windows of the write sink are whole blocks; interleaved launches take any window range
     partition_windows(p->n_windows, n_shards, step, rpw, tile_api, &p->shard_info);
     for (uint32_t g = 0; g < n_shards; ++g) p->shard_info[g].device = n_shards > 1 ? opt.shard_device[g] : p->device;
     if (n_shards > 1) {
@@ -1563,7 +1641,7 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->raw_per_window = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
     info->raw_step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D;
     info->ratio = p->ratio;
-    info->tile_windows = p->geo.G;
+    info->tile_windows = p->spark_R > 1 ? 1u : p->geo.G;
     if (p->cmp_a) {                                   // two-stage plan: the kernel figures are stage A's (the filter)
         qd_plan_info ia;
         const int rc = qd_plan_get_info(p->cmp_a, &ia);

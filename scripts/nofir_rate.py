@@ -9,7 +9,11 @@ import quadrs_amd as Q
 
 log2 = int(sys.argv[1]) if len(sys.argv) > 1 else 31
 dev = torch.device("cuda", 0)
-for fmt, shift, W, S in ((0, None, 128, 128), (0, 280000, 128, 128), (0, None, 1024, 1024), (0, 280000, 64, 16), (1, 280000, 256, 256), (0, None, 4, 2), (0, 280000, 16, 16), (0, 280000, 64, 64), (0, 280000, 256, 256), (3, 280000, 512, 512)):
+only_overlap = len(sys.argv) > 2 and sys.argv[2] == "overlap"
+for fmt, shift, W, S in ((0, None, 128, 128), (0, 280000, 128, 128), (0, None, 1024, 1024), (0, 280000, 64, 16), (1, 280000, 256, 256), (0, None, 4, 2), (0, 280000, 16, 16), (0, 280000, 64, 64), (0, 280000, 256, 256), (3, 280000, 512, 512),
+                        (0, None, 64, 16), (0, None, 128, 64), (0, None, 1024, 256), (1, None, 64, 16), (3, None, 256, 128)):
+    if only_overlap and (S == W or shift is not None):
+        continue
     n = 1 << (log2 + (2 if fmt == 1 else 0) - (3 if S < W else 0))
     src = bench.synth_slab(torch, fmt, 0, n, 0x5EED0002, dev)
     p = Q.Plan(fmt, 21_000_000, n, shift_hz=shift, width=W, stride=S)

@@ -812,6 +812,58 @@ def test_wave_local_kernel_equals_generic_and_oracle(engine, oracle, fmt, shift)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [0, 1, 3])
+def test_overlapping_windows_without_lowpass_as_interleaved_launches(engine, oracle, fmt):
+    """`from F sparkfft -width W -stride S` with S | W, S < W and nothing in front (README example 1: `-width 4 -stride 2`; src/fft.rs:28-65
+    over SampleFile): the windows phi, phi + W/S, ... lie side by side in the stream shifted by phi S samples, so a plan-time build of the
+    wave-local kernel runs W/S times, each launch writing every (W/S)-th output row.  Against the generic kernel and the oracle bit for
+    bit: norms and glyphs, streams that end anywhere, window sub-ranges that start in any phase, slabs that start inside the stream and
+    device slabs off the load-vector grid (those take the per-sample kernel)."""
+    import torch
+    from quadrs_amd import _ffi
+    bps = {0: 8, 1: 2, 3: 4}[fmt]
+    spl = {0: 2, 1: 4, 3: 4}[fmt]
+    sr = 21_000_000
+    for W, S in ((4, 2), (8, 4), (16, 4), (64, 16), (128, 64), (256, 32), (512, 256), (1024, 512), (1024, 32)):
+        n = 9 * 1024 + 3 * W + 5
+        data = _synth_bytes(fmt, n, 77 * fmt + W + S)
+        ch = oracle.Chain.from_bytes(data, fmt, sr)
+        ref, _ = ch.spark_fft(W, S)
+        for epi, rng_ in ((engine.EPI_NORMS_F32, None), (engine.EPI_GLYPH_U8, (0.01, 0.5) if fmt == 0 else (0.3, 30.0))):
+            kw = dict(width=W, stride=S, epilogue=epi, rng=rng_)
+            j = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_SPECIALISE, **kw)
+            g = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_GENERIC, **kw)
+            expect_phases = W >= spl and (S * bps) % 4 == 0
+            assert bool(j.info.kernel_flags & 524288) == expect_phases, (fmt, W, S, j.info.kernel_flags)
+            if expect_phases:
+                assert j.info.kernel_kind == 2 and j.info.tile_windows == 1
+                assert bool(j.info.kernel_flags & 1048576) == (fmt == 0 and W in (128, 256, 512, 1024))
+            a, b = j.run_host(data), g.run_host(data)
+            assert a.shape == b.shape and np.array_equal(a, b), (fmt, W, S, epi, int((a != b).sum()))
+            if epi != engine.EPI_NORMS_F32:
+                j.close(); g.close()
+                continue
+            assert ref.shape == a.shape and bits_equal(ref, a), (fmt, W, S)
+            nw, R = j.n_windows, W // S
+            for w0 in sorted({1, R - 1, R, R + 1, nw // 2, nw - 1, nw - R - 1}):
+                for cnt in sorted({1, min(R + 1, nw - w0), nw - w0}):
+                    first, count = j.src_range(w0, cnt)
+                    sub = j.run_host(data[first * bps:(first + count) * bps], w0, cnt, src_first=first)
+                    assert np.array_equal(sub, a[w0:w0 + cnt]), (fmt, W, S, w0, cnt)
+            # a device slab whose first sample is not on the load-vector grid
+            w0 = max(1, nw // 3)
+            first, count = j.src_range(w0, nw - w0)
+            if first % spl == 0:
+                first -= 1; count += 1
+            src = torch.frombuffer(bytearray(data[first * bps:(first + count) * bps]), dtype=torch.uint8).cuda()
+            out = torch.empty(nw - w0, W, dtype=torch.float32, device="cuda")
+            j.run_device(src, out, w0, nw - w0, src_first=first, src_count=count)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), a[w0:]), (fmt, W, S, "unaligned slab")
+            j.close(); g.close()
+
+
+@pytest.mark.gpu
 def test_wave_local_kernel_many_tiles(engine, oracle):
     """More tiles than resident waves (grid-stride walk, prefetch of the next tile, the last wave's short run): 2^24 cf32 samples,
     W = 128 with and without a shift, against the generic kernel bit for bit and against the oracle on sampled windows."""
