@@ -154,7 +154,7 @@ typedef struct {
     uint64_t raw_per_window;  /* W*D + T source samples one window reads */
     uint64_t raw_step;        /* S*D source samples between window starts */
     double   ratio;           /* Shift ratio (0 if no shift) */
-    uint32_t tile_windows;    /* windows per workgroup tile (1 for overlapping lowpass-free windows served by interleaved launches: any range) */
+    uint32_t tile_windows;    /* windows per workgroup tile (overlapping lowpass-free windows served by interleaved launches: any range; ranges starting on multiples of this keep the fast path) */
     uint32_t threads;         /* workgroup size */
     uint32_t lds_bytes;
     uint32_t kernel_kind;     /* 0 generic (runtime geometry), 1 built-in shape-specialised, 2 specialised at plan time (hiprtc) */

@@ -3310,10 +3310,13 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
 // With a shift: the lane's samples sit at 2 base different places j of their NCO row (rows of 512 samples), so the lane constants
 // (cos, sin)(j ratio) come from an LDS copy of the lane table (one ds_read_b128 per sample) instead of 64 registers, the row base is
 // selected per lane from the tile's rows; same table entries, same operations as k_chain: bit-identical output.
-// cf32, W = 128 ... 1024 (width 16 or 64); everything else stays on k_spark.  Tile: 64 lanes x 2 columns x base rows = 1024 samples
-// (base 8: W = 128, 512) or 2048 (base 16: W = 256, 1024).
+// W = 128 ... 1024 (width 16 or 64), every format (the integer formats' rows arrive packed: 4 or 8 bytes per lane and row); everything
+// else stays on k_spark.  Tile: 64 lanes x 2 columns x base rows = 1024 samples (base 8: W = 128, 512) or 2048 (base 16: W = 256, 1024).
 constexpr uint32_t kGeoSparkReg = 1048576;   // FLAGS bit 20
 
+template <int FMT> struct Spark2Raw { using type = uint32_t; };          // a row's column pair as loaded: one dword (cs8 / cu8) ...
+template <> struct Spark2Raw<0> { typedef unsigned type __attribute__((ext_vector_type(4))); };       // ... four (cf32) ...
+template <> struct Spark2Raw<3> { typedef unsigned type __attribute__((ext_vector_type(2))); };       // ... two (cs16)
 template <class GeoT> struct Spark2 {
     static constexpr uint32_t W = GeoT::W, base = GeoT::base_len, layers = GeoT::layers, width = W / base;
     static constexpr uint32_t LPW = width / 2, GW = 64 / (LPW ? LPW : 1), TS = GW * W, NBF = TS / 256;   // lanes per window, windows per tile, butterflies per lane and layer
@@ -3322,11 +3325,13 @@ template <class GeoT> struct Spark2 {
     static constexpr uint32_t lds_bytes(bool shift) { return ((W < 16u ? 16u : W) + 4u * TS) * 8u + (shift ? kSparkRow * 16u : 0u); }
 };
 
-template <int NCO, class GeoT, int LB, int EPI /* the plan's qd_epilogue, compile-time: the tile loop carries no sink dispatch */>
+template <int FMT, int NCO, class GeoT, int LB, int EPI /* the plan's qd_epilogue, compile-time: the tile loop carries no sink dispatch */>
 __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
     using K = Spark2<GeoT>;
-    static_assert(K::ok, "k_spark2: cf32, stride == width, W = base * 16 or base * 64");
+    using FT = FmtTraits<FMT>;
+    static_assert(K::ok, "k_spark2: stride == width, W = base * 16 or base * 64");
     constexpr bool HAS_SHIFT = NCO != 0;
+    constexpr uint32_t BPS = FT::BPS;                                      // a lane's column pair is 2 BPS bytes of a row: 16 (cf32), 8 (cs16) or 4 (cs8 / cu8)
     constexpr uint32_t W = K::W, logW = GeoT::logW, base = K::base, layers = K::layers, width = K::width, LPW = K::LPW, GW = K::GW, TS = K::TS, NBF = K::NBF;
     const GeoT geo(P);
 
@@ -3376,17 +3381,32 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
     const uint64_t n_waves = walk.stride, tile_end = walk.end;
     if (tile >= tile_end) return;
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     auto rsrc_of = [&](uint64_t t) {
         const uint64_t ns = (P.first_window + t * GW) << logW, end = P.src_first + P.src_count;
-        const uint64_t left = ns < end ? (end - ns) * 8 : 0;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * 8, 0,
+        const uint64_t left = ns < end ? (end - ns) * BPS : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * BPS, 0,
                                                  left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
     };
-    const uint32_t voff = (g * W + 2 * xp) * 8;                             // lane's byte offset inside a row of its window
-    v4u_t raw[base];
+    const uint32_t voff = (g * W + 2 * xp) * BPS;                           // lane's byte offset inside a row of its window
+    // the integer formats arrive packed: a row's column pair is one dword (8-bit) or two (cs16), unpacked one column at a time in pass 1
+    // — rows of 2 width bytes (8-bit, W = 128 / 256: 32 B per window and instruction; the row loads of a tile walk its cache lines in
+    // order, each line is fetched from L2 once)
+    using Raw = typename Spark2Raw<FMT>::type;
+    Raw raw[base];
     auto load_rows = [&](const decltype(rsrc_of(0)) &rsrc) {
 #pragma unroll
-        for (uint32_t y = 0; y < base; ++y) raw[y] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(y * width * 8), 2 /* nt */);
+        for (uint32_t y = 0; y < base; ++y) {
+            if constexpr (FMT == 0) raw[y] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(y * width * BPS), 2 /* nt */);
+            else if constexpr (FMT == 3) raw[y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(y * width * BPS), 2);
+            else raw[y] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(y * width * BPS), 2);
+        }
+    };
+    auto column = [&](uint32_t y, int u) -> float2 {                        // sample (row y, column 2 xp + u) as the chain's unpack delivers it (src/lib.rs:241-255)
+        if constexpr (FMT == 0) return u == 0 ? make_float2(__uint_as_float(raw[y].x), __uint_as_float(raw[y].y)) : make_float2(__uint_as_float(raw[y].z), __uint_as_float(raw[y].w));
+        else if constexpr (FMT == 1) { const uint32_t a = raw[y] ^ 0x80808080u; return u == 0 ? make_float2(unpack_cs8_at(a, 0), unpack_cs8_at(a, 1)) : make_float2(unpack_cs8_at(a, 2), unpack_cs8_at(a, 3)); }
+        else if constexpr (FMT == 2) return u == 0 ? make_float2(unpack_cu8_at(raw[y], 0), unpack_cu8_at(raw[y], 1)) : make_float2(unpack_cu8_at(raw[y], 2), unpack_cu8_at(raw[y], 3));
+        else { const uint32_t w = u == 0 ? raw[y].x : raw[y].y; return make_float2(unpack_cs16(w & 0xffffu), unpack_cs16(w >> 16)); }
     };
     load_rows(rsrc_of(tile));
     if constexpr (EPI != 2) {
@@ -3435,7 +3455,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
             float2 v[base];
 #pragma unroll
             for (uint32_t y = 0; y < base; ++y) {
-                float2 x = u == 0 ? make_float2(__uint_as_float(raw[y].x), __uint_as_float(raw[y].y)) : make_float2(__uint_as_float(raw[y].z), __uint_as_float(raw[y].w));
+                float2 x = column(y, u);
                 if constexpr (HAS_SHIFT) {
                     const uint32_t jrow = (W >= kSparkRow ? 0u : (g * W) % kSparkRow) + (y * width) % kSparkRow;      // sample's place in its NCO row (before the column)
                     const uint32_t j = jrow + 2 * xp + (uint32_t)u;

@@ -473,7 +473,7 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
     }
     char name[512];
     if ((k.flags & kGeoSpark) && (k.flags & kGeoSparkReg))      // ... with the first FFT pass out of registers (cf32, W = 128 ... 1024)
-        snprintf(name, sizeof name, "qd::k_spark2<%d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.nco, k.W,
+        snprintf(name, sizeof name, "qd::k_spark2<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
                  k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.lb, k.epi);
     else
     if (k.flags & kGeoSpark)       // the wave-local kernel of chains without a lowpass: rch = chunks per tile
@@ -707,6 +707,7 @@ struct qd_plan {
     uint32_t spark_ts = 0;               // ... its tile: samples per wave (512, 1024 or 2048)
     int spark_lb = 4;                    // ... waves per SIMD it is register-budgeted for (= workgroups per CU)
     bool spark_jt_lds = false;           // ... plan-time k_spark with a shift: the lane table sits in LDS (8 KiB more)
+    uint32_t phase_unit = 1;             // ... window ranges that start on multiples of it start on a load vector
     uint32_t spark_R = 0;                // ... overlapping windows (stride divides width, no shift): W / S interleaved launches of side-by-side windows; 0: none
     bool spark = false;                  // the wave-local kernel of chains without a lowpass (k_spark) is this plan's main kernel
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
@@ -1303,8 +1304,8 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         p->nt = (int)(kSparkRow / spl_of(d.format));      // NCO rows of 512 samples: row table and lane table are laid out for that
         kflags = kGeoSpark;
         p->spark_lb = spark_lb(p->spark_ts, p->nco);
-        if (jit_ok && d.format == QD_FMT_CF32 && (p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024)) {
-            // cf32, width 16 or 64 columns: the plan-time kernel that runs the base butterflies out of the row registers (k_spark2);
+        if (jit_ok && (p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024)) {
+            // width 16 or 64 columns: the plan-time kernel that runs the base butterflies out of the row registers (k_spark2);
             // tile = 64 lanes x 2 columns x base rows.  Cached builds always, a new one for streams of 1 GiB and more.
             // (the kernel's own geometry is windows side by side: S = W also where the plan's windows overlap, see spark_R)
             const uint32_t fbase = (ilog2(p->W) & 1) ? 8u : 16u, ts2 = 128u * fbase, g2 = ts2 / p->W;
@@ -1589,7 +1590,9 @@ int qd_plan_create_ex(const qd_chain_desc *desc, const qd_plan_options *options,
     // sharded plans: the parent describes the whole stream; each shard gets a plan of its own on its device
     const uint32_t n_shards = opt.n_shards > 1 ? opt.n_shards : 1;
     const uint64_t step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D, rpw = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
-    const uint32_t tile_api = (p->blk_len || p->spark_R > 1) ? 1u : p->geo.G;        // API windows of the write sink are whole blocks; interleaved launches take any window range
+    // API windows of the write sink are whole blocks; interleaved launches take any window range, and keep their speed when it starts on a load vector
+    uint32_t tile_api = p->blk_len ? 1u : p->geo.G;
+    if (p->spark_R > 1) { tile_api = (uint32_t)spl_of(d.format); while (tile_api > 1 && ((uint64_t)(tile_api / 2) * p->S) % spl_of(d.format) == 0) tile_api /= 2; p->phase_unit = tile_api; }
     partition_windows(p->n_windows, n_shards, step, rpw, tile_api, &p->shard_info);
     for (uint32_t g = 0; g < n_shards; ++g) p->shard_info[g].device = n_shards > 1 ? opt.shard_device[g] : p->device;
     if (n_shards > 1) {
@@ -1641,7 +1644,7 @@ int qd_plan_get_info(const qd_plan *p, qd_plan_info *info) {
     info->raw_per_window = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
     info->raw_step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D;
     info->ratio = p->ratio;
-    info->tile_windows = p->spark_R > 1 ? 1u : p->geo.G;
+    info->tile_windows = p->spark_R > 1 ? p->phase_unit : p->geo.G;
     if (p->cmp_a) {                                   // two-stage plan: the kernel figures are stage A's (the filter)
         qd_plan_info ia;
         const int rc = qd_plan_get_info(p->cmp_a, &ia);

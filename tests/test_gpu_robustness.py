@@ -772,12 +772,12 @@ def test_wave_local_kernel_equals_generic_and_oracle(engine, oracle, fmt, shift)
             assert p.n_windows == g.n_windows
             a, b = p.run_host(data), g.run_host(data)
             assert np.array_equal(a, b), (fmt, shift, W, epi, int((a != b).sum()))
-            if fmt == 0 or W in (4, 64, 256):
-                # the plan-time builds (what a stream of 1 GiB and more gets): width as a compile-time constant, and for cf32 at
-                # W = 128 ... 1024 the kernel whose base butterflies run out of the row registers (bit 20)
+            if fmt == 0 or W in (4, 64, 256) or (W in (128, 512, 1024) and epi == engine.EPI_NORMS_F32):
+                # the plan-time builds (what a stream of 1 GiB and more gets): width as a compile-time constant, and at W = 128 ... 1024
+                # the kernel whose base butterflies run out of the row registers (bit 20; every format)
                 j = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_SPECIALISE, **kw)
                 assert j.info.kernel_kind == 2 and j.info.kernel_flags & 524288
-                assert bool(j.info.kernel_flags & 1048576) == (fmt == 0 and W in (128, 256, 512, 1024)), (W, j.info.kernel_flags)
+                assert bool(j.info.kernel_flags & 1048576) == (W in (128, 256, 512, 1024)), (W, j.info.kernel_flags)
                 c = j.run_host(data)
                 assert np.array_equal(c, b), (fmt, shift, W, epi, "plan-time build", int((c != b).sum()))
                 if epi == engine.EPI_NORMS_F32:
@@ -836,8 +836,8 @@ def test_overlapping_windows_without_lowpass_as_interleaved_launches(engine, ora
             expect_phases = W >= spl and (S * bps) % 4 == 0
             assert bool(j.info.kernel_flags & 524288) == expect_phases, (fmt, W, S, j.info.kernel_flags)
             if expect_phases:
-                assert j.info.kernel_kind == 2 and j.info.tile_windows == 1
-                assert bool(j.info.kernel_flags & 1048576) == (fmt == 0 and W in (128, 256, 512, 1024))
+                assert j.info.kernel_kind == 2 and j.info.tile_windows == max(1, spl // S)
+                assert bool(j.info.kernel_flags & 1048576) == (W in (128, 256, 512, 1024))
             a, b = j.run_host(data), g.run_host(data)
             assert a.shape == b.shape and np.array_equal(a, b), (fmt, W, S, epi, int((a != b).sum()))
             if epi != engine.EPI_NORMS_F32:
