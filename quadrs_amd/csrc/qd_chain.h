@@ -3091,6 +3091,110 @@ struct SparkWalk {
     }
 };
 
+// LDS swizzle of the wave's transform buffer (plan-time builds, widths 8 ... 64).  Unswizzled, the buffer's accesses conflict: the
+// scatter into transposed order 2- to 4-way, the base butterflies' 16-byte pieces (a lane owns a run of `base` points: lane stride 64 or
+// 128 B) 4- to 8-way on every read and write, the first radix-4 layer 2- to 4-way — rocprofv3 on cf32 W = 64 with a shift: the LDS array busy
+// 84 % of the kernel's cycles, 59 % of them conflicts (profiles/r04/nofir_pmc_spark_v1.log).  sigma(p) = p ^ M p with M a GF(2) matrix
+// that only feeds HIGHER index bits into bits 1 ... 4 (a bijection; bit 0 untouched, so 16-byte pieces stay whole; sources >= log2(base),
+// so a run sees one XOR value).  m[d - 1] = the source bits XORed into bit d, found per (W, SPL) by scripts/lds_swizzle_search.py over
+// every LDS instruction of a 512- and a 1024-sample tile under the bank rules of MI355X_MICROARCH.md (lane-group cycles, identity -> map;
+// conflict-free = 1x):
+template <uint32_t W, uint32_t SPL> struct SparkSwz { static constexpr uint32_t m[4] = {0, 0, 0, 0}; };
+template <> struct SparkSwz<64, 2> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };   // 3.30x -> 0.90x (some groups idle)
+template <> struct SparkSwz<32, 2> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x30, 0x40}; };    // 2.78x -> 1.00x
+template <> struct SparkSwz<16, 2> { static constexpr uint32_t m[4] = {0x10, 0x20, 0x40, 0x80}; };   // 4.14x -> 1.14x
+template <> struct SparkSwz<8, 2> { static constexpr uint32_t m[4] = {0x50, 0x20, 0x0, 0x0}; };      // 2.83x -> 1.33x
+template <> struct SparkSwz<64, 4> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };   // 3.10x -> 0.90x
+template <> struct SparkSwz<32, 4> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x20, 0x40}; };    // 2.78x -> 1.00x
+template <> struct SparkSwz<16, 4> { static constexpr uint32_t m[4] = {0x10, 0x20, 0x40, 0x80}; };   // 4.71x -> 1.14x
+template <> struct SparkSwz<8, 4> { static constexpr uint32_t m[4] = {0x50, 0x20, 0x0, 0x0}; };      // 3.50x -> 1.33x
+template <class SZ> struct SparkSwzFn {
+    // the sources at distance `off` above their destination, as a mask over the destination bits
+    static constexpr uint32_t mask_off(uint32_t off) {
+        uint32_t r = 0;
+        for (uint32_t d = 1; d <= 4; ++d) if ((SZ::m[d - 1] >> (d + off)) & 1u) r |= 1u << d;
+        return r;
+    }
+    // sigma(p) ^ p.  GF(2)-linear: delta(a | b) = delta(a) ^ delta(b) for disjoint a, b — callers split an index into a per-lane part
+    // (formed once per tile) and a compile-time part (folded)
+    static __device__ __forceinline__ constexpr uint32_t delta(uint32_t p) {
+        constexpr uint32_t k1 = mask_off(1), k2 = mask_off(2), k3 = mask_off(3), k4 = mask_off(4), k5 = mask_off(5), k6 = mask_off(6), k7 = mask_off(7), k8 = mask_off(8);
+        return ((p >> 1) & k1) ^ ((p >> 2) & k2) ^ ((p >> 3) & k3) ^ ((p >> 4) & k4) ^ ((p >> 5) & k5) ^ ((p >> 6) & k6) ^ ((p >> 7) & k7) ^ ((p >> 8) & k8);
+    }
+};
+
+// The transform of a wave's tile in the swizzled layout: base butterflies on 16-byte pieces, radix-4 layers in place (W >= 8, compile-time
+// geometry; the arithmetic and its order are wave_fft_epilogue_fn's).  Addresses are LDS BYTE offsets: the buffer starts on a 256-byte
+// boundary (k_spark checks), so the swizzle's XORs (index bits 1 ... 4 = byte bits 4 ... 7) apply to the byte address directly — one v_xor
+// per access on top of a per-lane base, instead of an XOR, a shift and an add.
+typedef float spark_f2n __attribute__((ext_vector_type(2)));
+typedef float spark_f4n __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) spark_f2n spark_lds_f2;
+typedef __attribute__((address_space(3))) spark_f4n spark_lds_f4;
+__device__ __forceinline__ float2 spark_ld2(uint32_t a) { const spark_f2n v = *(const spark_lds_f2 *)(uintptr_t)a; return make_float2(v.x, v.y); }
+__device__ __forceinline__ void spark_st2(uint32_t a, float2 v) { *(spark_lds_f2 *)(uintptr_t)a = spark_f2n{v.x, v.y}; }
+
+template <class GeoT, uint32_t TS, uint32_t SPL>
+__device__ __forceinline__ void spark_fft_swz(const ChainParams &P, const float2 *twl, uint32_t fb /* LDS byte offset of the wave's buffer */, uint32_t lane_in) {
+    using SZ = SparkSwzFn<SparkSwz<GeoT::W, SPL>>;
+    constexpr uint32_t base = GeoT::base_len, lb = GeoT::log_base, layers = GeoT::layers;
+    static_assert(base == 8 || base == 16, "spark_fft_swz: W >= 8");
+    uint32_t lo = lane_in;
+    asm volatile("" : "+v"(lo));            // opaque per tile: addresses are rebuilt, not hoisted out of the tile loop and spilled
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    constexpr uint32_t n_task = TS / base;
+#pragma unroll
+    for (uint32_t k = 0; k < (n_task + 63) / 64; ++k) {
+        const uint32_t t = lo + 64 * k;
+        if (n_task % 64 == 0 || t < n_task) {
+            const uint32_t r0 = t << lb, a0 = fb + ((r0 ^ SZ::delta(r0)) << 3);          // piece q of the run sits at a0 ^ 16 q
+            float2 v[base];
+#pragma unroll
+            for (uint32_t q = 0; q < base / 2; ++q) {
+                const spark_f4n pc = *(const spark_lds_f4 *)(uintptr_t)(a0 ^ (16 * q));
+                v[2 * q] = make_float2(pc.x, pc.y); v[2 * q + 1] = make_float2(pc.z, pc.w);
+            }
+            if constexpr (base == 16) bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2); else bf8(v, P.root2);
+            uint32_t a1 = a0;
+            asm volatile("" : "+v"(a1));        // the piece addresses are formed again (one XOR each) instead of held across the butterfly
+#pragma unroll
+            for (uint32_t q = 0; q < base / 2; ++q)
+                *(spark_lds_f4 *)(uintptr_t)(a1 ^ (16 * q)) = spark_f4n{v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y};
+        }
+    }
+    uint32_t cols = base, log_cols = lb, tw_off = 0;
+#pragma unroll
+    for (uint32_t l = 0; l < layers; ++l) {
+        wsync();
+        // layers of at most 64 columns: a lane's butterflies t = lane + 64 k share i = t mod cols, hence their three twiddles
+        float2 tc1 = make_float2(0.f, 0.f), tc2 = tc1, tc3 = tc1;
+        if (cols <= 64) { const uint32_t i = lo & (cols - 1); tc1 = twl[tw_off + 3 * i]; tc2 = twl[tw_off + 3 * i + 1]; tc3 = twl[tw_off + 3 * i + 2]; }
+#pragma unroll
+        for (uint32_t k = 0; k < TS / 256; ++k) {
+            const uint32_t t = lo + 64 * k, chunk = t >> log_cols, i = t & (cols - 1);
+            const uint32_t p0 = chunk * 4 * cols + i, b0 = fb + ((p0 ^ SZ::delta(p0)) << 3);
+            uint32_t dp[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                // q cols: index bits log_cols, log_cols + 1, zero in p0.  Bits below 5 (and the XOR value, bits 1 ... 4) go in by XOR — inside the
+                // low 256 bytes, where the 256-byte-aligned base contributes nothing —, bits from 5 up by addition (an instruction offset)
+                const uint32_t qc = q * cols, lo_q = (qc ^ SZ::delta(qc)) & 31u, hi_q = qc & ~31u;
+                dp[q] = (b0 ^ (lo_q << 3)) + (hi_q << 3);
+            }
+            float2 t1 = tc1, t2 = tc2, t3 = tc3;
+            if (cols > 64) { t1 = twl[tw_off + 3 * i]; t2 = twl[tw_off + 3 * i + 1]; t3 = twl[tw_off + 3 * i + 2]; }
+            float2 s0 = spark_ld2(dp[0]);
+            float2 s1 = cmul(spark_ld2(dp[1]), t1);
+            float2 s2 = cmul(spark_ld2(dp[2]), t2);
+            float2 s3 = cmul(spark_ld2(dp[3]), t3);
+            bf4(s0, s1, s2, s3);
+            spark_st2(dp[0], s0); spark_st2(dp[1], s1); spark_st2(dp[2], s2); spark_st2(dp[3], s3);
+        }
+        tw_off += 3 * cols; cols *= 4; log_cols += 2;
+    }
+    wsync();
+}
+
 template <int FMT> struct SparkTraits {
     using FT = FmtTraits<FMT>;
     static constexpr uint32_t SPL = FT::SPL, CH = 64u * SPL, RQ = kSparkRow / CH;       // chunk: one wave-wide load; RQ chunks per NCO row
@@ -3116,8 +3220,8 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
     // Plan-time builds with a shift read the lane constants out of an LDS copy of the lane table (one ds_read_b128 per sample) instead of
     // holding RQ * SPL (cos, sin) pairs — 32 registers — across the tile loop: that is what kept them at three waves per SIMD.
     constexpr bool kLdsLane = HAS_SHIFT && GeoT::kFixed;
-    double2 *jt = reinterpret_cast<double2 *>(twl + (W < 16u ? 16u : W));
-    float2 *fbw = twl + (W < 16u ? 16u : W) + (kLdsLane ? 2u * kSparkRow : 0u) + (size_t)wave * TS;           // this wave's transform buffer: TS complex samples
+    double2 *jt = reinterpret_cast<double2 *>(twl + (W < 32u ? 32u : W));      // (twiddle area of at least 256 bytes: the transform buffers start on 256-byte boundaries)
+    float2 *fbw = twl + (W < 32u ? 32u : W) + (kLdsLane ? 2u * kSparkRow : 0u) + (size_t)wave * TS;           // this wave's transform buffer: TS complex samples
     {
         const uint32_t n_tw = W - geo.base_len;
         for (uint32_t i = tid; i < n_tw; i += kThreads) twl[i] = P.tw[i];
@@ -3138,6 +3242,17 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
                 const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
                 pos[c * SPL + u] = (m & ~(W - 1)) + yy + (rev4(xx, geo.layers) << geo.log_base);
             }
+    }
+    // plan-time builds with the sink known (the lean path below), W >= 8: the transform buffer in the swizzled layout (SparkSwz)
+    constexpr bool kLeanEpi = GeoT::kFixed && (EPI == 0 || EPI == 1);
+    const uint32_t fb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)fbw;      // LDS byte offset of the wave's buffer
+    if (kLeanEpi && (fb_off & 255u)) __builtin_trap();                      // (dynamic LDS starts at offset 0: never taken; the swizzled addressing relies on it)
+    if constexpr (kLeanEpi) {
+        if constexpr (GeoT::W >= 8) {
+            using SZ = SparkSwzFn<SparkSwz<GeoT::W, (uint32_t)SPL>>;
+#pragma unroll
+            for (int i = 0; i < NCH * SPL; ++i) pos[i] ^= SZ::delta(pos[i]);
+        }
     }
     // (cos, sin)(j * ratio) of the lane's sample slots in each row quarter; the slot index itself is kept for quarter 0 only — the
     // quarter's offset q * CH goes into the row's sample count instead (integers below 2^53: the same double whichever way they add up)
@@ -3254,20 +3369,29 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
         }
         wsync();
         if constexpr (kLean) {
-            wave_fft_epilogue_fn<GeoT, 0, 3>(P, geo, twl, fbw, w0, G, tid);          // every window of the tile (rows past the slab read as zeros): compile-time trip counts
+            // every window of the tile (rows past the slab read as zeros): compile-time trip counts
+            if constexpr (GeoT::W >= 8) spark_fft_swz<GeoT, TS, (uint32_t)SPL>(P, twl, fb_off, lane);
+            else wave_fft_epilogue_fn<GeoT, 0, 3>(P, geo, twl, fbw, w0, G, tid);
             constexpr uint32_t OBW = EPI == 0 ? 4u * GeoT::W : GeoT::W;
             const uint32_t RS = P.out_row_stride ? P.out_row_stride : 1u;      // rows between this launch's windows (interleaved launches of overlapping windows)
             const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * RS * OBW, 0,
                                                                  g_cnt ? ((g_cnt - 1) * RS + 1) * OBW : 0u, 0x00020000);
             uint32_t lo = lane;
             asm volatile("" : "+v"(lo));
+            // element (lo + 64 k) ^ (W / 2) of the swizzled buffer: the lane's bits and the compile-time ones swizzle separately (delta is linear)
+            using SZE = SparkSwzFn<SparkSwz<(GeoT::W >= 8 ? GeoT::W : 0u), (uint32_t)SPL>>;
+            const uint32_t el = lo ^ ((GeoT::W >> 1) & 63u), e0 = fb_off + ((el ^ SZE::delta(el)) << 3);
 #pragma unroll
             for (uint32_t k0 = 0; k0 < NB; k0 += 4) {
                 float nm[4];
                 bool sl[4];
                 float2 xv[4];
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) xv[q] = fbw[(lo + 64 * (k0 + q)) ^ (GeoT::W >> 1)];      // fftshift: bin (b + W/2) mod W of the same window
+                for (uint32_t q = 0; q < 4; ++q) {                          // fftshift: bin (b + W/2) mod W of the same window
+                    constexpr uint32_t hi_w = (GeoT::W >> 1) & ~63u;
+                    const uint32_t ec = (64 * (k0 + q)) ^ hi_w;
+                    xv[q] = spark_ld2((e0 ^ (SZE::delta(ec) << 3)) + (ec << 3));      // XOR value: byte bits 4 ... 7, below the 256-byte-aligned base; ec: an instruction offset
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) nm[q] = norm_fast(xv[q].x, xv[q].y, sl[q]);
                 if (__builtin_expect(sl[0] | sl[1] | sl[2] | sl[3], 0)) {

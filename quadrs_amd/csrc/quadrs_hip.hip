@@ -1354,7 +1354,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
         raw_elems = re_gen;
     }
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
-    if (p->spark) p->geo.lds_main = ((size_t)(p->W < 16 ? 16 : p->W) + 4 * (size_t)p->spark_ts) * 8 +     // twiddles | four waves' transform buffers (k_spark)
+    if (p->spark) p->geo.lds_main = ((size_t)(p->W < 32 ? 32 : p->W) + 4 * (size_t)p->spark_ts) * 8 +     // twiddles | four waves' transform buffers (k_spark)
                                     ((((kflags & kGeoSparkReg) && p->has_shift) || p->spark_jt_lds) ? (size_t)kSparkRow * 16 : 0);   // plan-time builds with a shift: + the NCO lane table
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);

@@ -772,7 +772,7 @@ def test_wave_local_kernel_equals_generic_and_oracle(engine, oracle, fmt, shift)
             assert p.n_windows == g.n_windows
             a, b = p.run_host(data), g.run_host(data)
             assert np.array_equal(a, b), (fmt, shift, W, epi, int((a != b).sum()))
-            if fmt == 0 or W in (4, 64, 256) or (W in (128, 512, 1024) and epi == engine.EPI_NORMS_F32):
+            if fmt == 0 or W in (4, 64, 256) or (W in (8, 16, 32, 128, 512, 1024) and epi == engine.EPI_NORMS_F32):
                 # the plan-time builds (what a stream of 1 GiB and more gets): width as a compile-time constant, and at W = 128 ... 1024
                 # the kernel whose base butterflies run out of the row registers (bit 20; every format)
                 j = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_SPECIALISE, **kw)
