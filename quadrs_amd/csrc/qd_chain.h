@@ -3444,7 +3444,8 @@ template <> struct Spark2Raw<3> { typedef unsigned type __attribute__((ext_vecto
 template <class GeoT> struct Spark2 {
     static constexpr uint32_t W = GeoT::W, base = GeoT::base_len, layers = GeoT::layers, width = W / base;
     static constexpr uint32_t LPW = width / 2, GW = 64 / (LPW ? LPW : 1), TS = GW * W, NBF = TS / 256;   // lanes per window, windows per tile, butterflies per lane and layer
-    static constexpr bool ok = GeoT::kFixed && (base == 8 || base == 16) && layers >= 1 && (width == 16 || width == 64) && GeoT::S == W && GeoT::D == 1 && GeoT::T == 0;
+    // (S < W: overlapping windows — each window's rows are loaded for it, the overlap comes out of the caches; HBM is read once)
+    static constexpr bool ok = GeoT::kFixed && (base == 8 || base == 16) && layers >= 1 && (width == 16 || width == 64) && GeoT::S <= W && GeoT::S >= 1 && GeoT::D == 1 && GeoT::T == 0;
     static constexpr uint32_t kRows = TS / kSparkRow;                  // NCO rows per tile (2 or 4)
     static constexpr uint32_t lds_bytes(bool shift) { return ((W < 16u ? 16u : W) + 4u * TS) * 8u + (shift ? kSparkRow * 16u : 0u); }
 };
@@ -3453,8 +3454,10 @@ template <int FMT, int NCO, class GeoT, int LB, int EPI /* the plan's qd_epilogu
 __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
     using K = Spark2<GeoT>;
     using FT = FmtTraits<FMT>;
-    static_assert(K::ok, "k_spark2: stride == width, W = base * 16 or base * 64");
+    static_assert(K::ok, "k_spark2: W = base * 16 or base * 64");
     constexpr bool HAS_SHIFT = NCO != 0;
+    constexpr uint32_t S = GeoT::S;                                         // samples between windows (== W: side by side)
+    static_assert(S == K::W || !HAS_SHIFT, "k_spark2: overlapping windows only without a shift (the NCO rows are laid out for whole tiles)");
     constexpr uint32_t BPS = FT::BPS;                                      // a lane's column pair is 2 BPS bytes of a row: 16 (cf32), 8 (cs16) or 4 (cs8 / cu8)
     constexpr uint32_t W = K::W, logW = GeoT::logW, base = K::base, layers = K::layers, width = K::width, LPW = K::LPW, GW = K::GW, TS = K::TS, NBF = K::NBF;
     const GeoT geo(P);
@@ -3507,12 +3510,12 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     auto rsrc_of = [&](uint64_t t) {
-        const uint64_t ns = (P.first_window + t * GW) << logW, end = P.src_first + P.src_count;
+        const uint64_t ns = (P.first_window + t * GW) * S, end = P.src_first + P.src_count;
         const uint64_t left = ns < end ? (end - ns) * BPS : 0;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * BPS, 0,
                                                  left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
     };
-    const uint32_t voff = (g * W + 2 * xp) * BPS;                           // lane's byte offset inside a row of its window
+    const uint32_t voff = (g * S + 2 * xp) * BPS;                           // lane's byte offset inside a row of its window
     // the integer formats arrive packed: a row's column pair is one dword (8-bit) or two (cs16), unpacked one column at a time in pass 1
     // — rows of 2 width bytes (8-bit, W = 128 / 256: 32 B per window and instruction; the row loads of a tile walk its cache lines in
     // order, each line is fetched from L2 once)

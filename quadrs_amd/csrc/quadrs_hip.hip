@@ -708,7 +708,8 @@ struct qd_plan {
     int spark_lb = 4;                    // ... waves per SIMD it is register-budgeted for (= workgroups per CU)
     bool spark_jt_lds = false;           // ... plan-time k_spark with a shift: the lane table sits in LDS (8 KiB more)
     uint32_t phase_unit = 1;             // ... window ranges that start on multiples of it start on a load vector
-    uint32_t spark_R = 0;                // ... overlapping windows (stride divides width, no shift): W / S interleaved launches of side-by-side windows; 0: none
+    bool spark_ov = false;               // ... overlapping windows without a lowpass or a shift on the wave-local kernels (plan-time builds only)
+    uint32_t spark_R = 0;                // ... as W / S interleaved launches of side-by-side windows (k_spark; stride divides width); <= 1: one launch (k_spark2)
     bool spark = false;                  // the wave-local kernel of chains without a lowpass (k_spark) is this plan's main kernel
     hipFunction_t jit_fn = nullptr;      // plan-time specialised kernel (hiprtc), replaces fn for aligned launches
     std::string jit_note;
@@ -912,7 +913,7 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     // row-aligned phase 1 with G S D (not S D) a multiple of the row: the launch's first window must sit on a row boundary too
     bool fast_misaligned = (p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
     // the wave-local kernel: tiles start on NCO rows when the chain shifts, on load vectors otherwise; irregular rows (take_fft) never run on it
-    if (p->spark) fast_misaligned = phases_unaligned || p->row_offsets_d != nullptr || ((first_window * p->W) % (p->has_shift ? (uint64_t)kSparkRow : (uint64_t)spl)) != 0;
+    if (p->spark) fast_misaligned = phases_unaligned || p->row_offsets_d != nullptr || ((first_window * p->S) % (p->has_shift ? (uint64_t)kSparkRow : (uint64_t)spl)) != 0;
     if (vec_ok && !fast_misaligned) {
         // windows [first_window, first_window + n_aligned): need-end rounded up to a vector fits in the slab
         const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
@@ -1106,13 +1107,20 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     const bool lut8 = d.format == QD_FMT_CS8 || d.format == QD_FMT_CU8;
     // chains without a lowpass whose windows lie side by side: the wave-local kernel (k_spark), for every width it holds in a tile
     p->spark = !p->has_fir && p->S == p->W && p->W <= kSparkMaxW && d.epilogue != QD_EPI_CF32_BLOCKS && policy != QD_KERNEL_GENERIC;
-    // ... and OVERLAPPING windows without a lowpass or a shift whose stride divides the width (`sparkfft -width 4 -stride 2`: README example 1,
-    // BASELINE configs[0]'s chain): the windows phi, phi + R, phi + 2R ... (R = W / S) lie side by side in the stream shifted by phi * S
-    // samples, so the chain is R launches of the same wave-local kernel, each writing every R-th output row.  Plan-time builds only (the
-    // row stride lives in their lean epilogue), norms and glyph sinks; everything else stays on k_chain.
-    if (!p->has_fir && !p->has_shift && p->S < p->W && p->W % p->S == 0 && p->W <= kSparkMaxW && p->W / p->S <= 32 &&
-        (d.epilogue == QD_EPI_NORMS_F32 || d.epilogue == QD_EPI_GLYPH_U8) && policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME &&
-        ((uint64_t)p->S * bps_of(d.format)) % 4 == 0 && p->W >= (uint32_t)spl_of(d.format)) { p->spark = true; p->spark_R = p->W / p->S; }
+    // ... and OVERLAPPING windows without a lowpass or a shift (`sparkfft -width 4 -stride 2`: README example 1, BASELINE configs[0]'s chain),
+    // as plan-time builds only:
+    //   * W = 128 ... 1024, any stride: ONE launch of k_spark2 built for the stride — every window's rows are loaded for it, the overlap
+    //     comes out of the caches;
+    //   * smaller widths whose stride divides them: the windows phi, phi + R, phi + 2R ... (R = W / S) lie side by side in the stream
+    //     shifted by phi * S samples, so the chain is R launches of k_spark, each writing every R-th output row (the row stride lives in
+    //     its lean epilogue: norms and glyph sinks).
+    // Everything else stays on k_chain.
+    if (!p->has_fir && !p->has_shift && p->S < p->W && p->W <= kSparkMaxW && d.epilogue != QD_EPI_CF32_BLOCKS &&
+        policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME && ((uint64_t)p->S * bps_of(d.format)) % 4 == 0 && p->W >= (uint32_t)spl_of(d.format)) {
+        const bool one_launch = p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024;
+        const bool phases = p->W % p->S == 0 && p->W / p->S <= 32 && (d.epilogue == QD_EPI_NORMS_F32 || d.epilogue == QD_EPI_GLYPH_U8);
+        if (one_launch || phases) { p->spark = true; p->spark_ov = true; p->spark_R = phases ? p->W / p->S : 1; }
+    }
     uint32_t tune[8] = {0, 0, 1, 8, 4, 1, 1, 0};
     uint32_t hint_flags = 0;
     bool tuned = false;
@@ -1310,20 +1318,23 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             // (the kernel's own geometry is windows side by side: S = W also where the plan's windows overlap, see spark_R)
             const uint32_t fbase = (ilog2(p->W) & 1) ? 8u : 16u, ts2 = 128u * fbase, g2 = ts2 / p->W;
             const int lb2 = p->has_shift ? (fbase == 8 ? 3 : 2) : (fbase == 8 ? 4 : 3);
-            JitKey k{d.format, p->nco, 0, 0, 1, lb2, kThreads, p->W, p->W, 1, 0, g2, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkReg, 0ull, d.epilogue};
+            // (overlapping windows, spark_R: this kernel takes them in ONE launch — every window's rows are loaded for it, the overlap is
+            // served by the caches —, so the stride goes into the build and the interleaved launches are off)
+            JitKey k{d.format, p->nco, 0, 0, 1, lb2, kThreads, p->W, p->S, 1, 0, g2, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkReg, 0ull, d.epilogue};
             if (hipFunction_t f = jit_chain_kernel(k, &p->jit_note, may_compile)) {
                 p->jit_fn = f; p->spark_ts = ts2; G = g2; kflags |= kGeoSparkReg; p->spark_lb = lb2;
+                p->spark_R = 0;
             }
         }
-        if (p->spark_R > 1 && !p->jit_fn) {
+        if (p->spark_ov && !p->jit_fn) {
             // interleaved launches need a plan-time build (k_spark with the sink as a template argument); none to be had: back to k_chain
             const int lbj = 4;
             JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, lbj, kThreads,
                      p->W, p->W, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull, d.epilogue};
-            p->jit_fn = jit_ok ? jit_chain_kernel(k, &p->jit_note, may_compile) : nullptr;
+            p->jit_fn = jit_ok && p->spark_R > 1 ? jit_chain_kernel(k, &p->jit_note, may_compile) : nullptr;
             if (p->jit_fn) p->spark_lb = lbj;
             else {
-                p->spark = false; p->spark_R = 0; p->spark_ts = 0; kflags = 0; p->nt = kThreads; G = 1;
+                p->spark = false; p->spark_ov = false; p->spark_R = 0; p->spark_ts = 0; kflags = 0; p->nt = kThreads; G = 1;
                 while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
                 while (G < 64 && (uint64_t)G * p->W < 1024 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 36 * 1024) G *= 2;
                 if (p->n_windows && G > p->n_windows) { while (G > 1 && G / 2 >= p->n_windows) G /= 2; }
