@@ -3438,6 +3438,15 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
 // else stays on k_spark.  Tile: 64 lanes x 2 columns x base rows = 1024 samples (base 8: W = 128, 512) or 2048 (base 16: W = 256, 1024).
 constexpr uint32_t kGeoSparkReg = 1048576;   // FLAGS bit 20
 
+// LDS swizzle of k_spark2's transform buffer: the same GF(2) maps as SparkSwz, searched over this kernel's LDS instructions (the base
+// pass's 16-byte piece writes of lane (g, xp), the layers' reads and writes; scripts/lds_swizzle_search2.py).  Base 16 (W = 256, 1024):
+// the hand-made swizzle the kernel started with, conflict-free in the model and on the counters; base 8 (W = 128, 512): the piece writes
+// were 4-way (lane-group cycles per tile 384 -> 192 and 480 -> 288).
+template <uint32_t W> struct Spark2Swz { static constexpr uint32_t m[4] = {0, 0, 0, 0}; };
+template <> struct Spark2Swz<128> { static constexpr uint32_t m[4] = {0x40, 0x10, 0x20, 0x40}; };
+template <> struct Spark2Swz<256> { static constexpr uint32_t m[4] = {0x80, 0x10, 0x20, 0x40}; };
+template <> struct Spark2Swz<512> { static constexpr uint32_t m[4] = {0x100, 0x20, 0x60, 0x40}; };
+template <> struct Spark2Swz<1024> { static constexpr uint32_t m[4] = {0x200, 0x40, 0x80, 0x40}; };
 template <int FMT> struct Spark2Raw { using type = uint32_t; };          // a row's column pair as loaded: one dword (cs8 / cu8) ...
 template <> struct Spark2Raw<0> { typedef unsigned type __attribute__((ext_vector_type(4))); };       // ... four (cf32) ...
 template <> struct Spark2Raw<3> { typedef unsigned type __attribute__((ext_vector_type(2))); };       // ... two (cs16)
@@ -3472,36 +3481,22 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
     if constexpr (HAS_SHIFT) { for (uint32_t i = tid; i < kSparkRow; i += kThreads) jt[i] = P.jtab[i]; }
     __syncthreads();                                                       // the only workgroup barrier
 
-    // LDS swizzle of the transform buffer.  The first layer (cols = base) reads point chunk * 4 base + k * base + i: the 32 lanes of a
-    // half-wave span i (log_base bits) and the low 5 - log_base bits of `chunk`, which lie above bit 5 of the index — every lane group
-    // of 8 (16) hits the same banks, a 4-way (2-way) conflict on all of that layer's reads and writes (rocprofv3, W = 128:
-    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 54 %).  XOR those chunk bits into the index bits just above i: a bijection that keeps
-    // runs of `base` points contiguous (the base pass still writes 16-byte pieces) and leaves the wider layers conflict-free.
+    // LDS swizzle of the transform buffer (Spark2Swz).  Unswizzled, the first layer (cols = base) reads point chunk * 4 base + k * base + i:
+    // the 32 lanes of a half-wave span i and the low bits of `chunk`, which lie above bit 5 of the index — a 4-way (2-way) conflict on all of
+    // that layer's reads and writes (rocprofv3, W = 128: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 54 %) —, and the base pass stores a
+    // lane's butterfly outputs as 16-byte pieces of one contiguous run, piece q of 8 lanes per instruction group: with runs of 64 (128)
+    // bytes a 4-way (8-way) conflict on every store of the pass.  The maps feed run- and chunk-index bits into index bits 1 ... 4 (whole
+    // pieces, one XOR value per run); sigma is linear, so a position splits into a per-lane part (XOR value formed once) and compile-time
+    // parts (folded), and with the buffers on 256-byte boundaries the XORs apply to the LDS byte address: one v_xor per access.
     // The bucket sink reads the buffer linearly afterwards: no swizzle there.
     constexpr bool kSwz = EPI != 2;
-    // ... and a second swizzle for the base pass's WRITES.  A lane stores its butterfly's `base` outputs as 16-byte pieces of one
-    // contiguous run; piece q of every lane goes out in the same instruction, 8 lanes to a group, and a group is conflict-free only if
-    // its 8 pieces fall into the 8 different 16-byte slots of the 128 bytes the banks span.  With runs of 64 (128) bytes the slot is
-    // (run & 1) * 4 + q (just q): 2 (1) distinct slots, a 4-way (8-way) conflict on every store of the pass.  So piece q of run r is
-    // kept at piece position q ^ f(r), f made of the run-index bits in which the 8 lanes of a group differ (x = 2 xp + u: x bit 1 is
-    // run bit 2 L - 1, x bits 2-3 are run bits 2 L - 4, 2 L - 3; L = layers): the layers read element (r, y) at the same place, whole
-    // runs stay whole, the first swizzle works on higher index bits.
-    auto piece_f = [](uint32_t r) -> uint32_t {
-        constexpr uint32_t L2 = 2 * layers;
-        // (measured, 16 GiB cf32: base 16 — W = 1024 6.45 -> 5.72 ms, W = 256 with a shift 6.25 -> 5.90; base 8 — W = 128 4.74 -> 4.81: its 4-way
-        // conflict costs less than the index arithmetic, so eight-point runs keep their pieces in order)
-        if constexpr (base == 8) return 0u;
-        else return ((r >> (L2 - 1)) & 1u) | (((r >> (L2 - 4)) & 3u) << 1);
-    };
-    auto sw = [&](uint32_t p) -> uint32_t {
-        constexpr uint32_t lb = GeoT::log_base, nb = 5 - lb;
-        if constexpr (!kSwz) return p;
-        const uint32_t r = (p >> lb) & (width - 1);                        // the run (base butterfly) the element belongs to, inside its window
-        return (p ^ (((p >> (lb + 2)) & ((1u << nb) - 1u)) << lb)) ^ (piece_f(r) << 1);
-    };
+    using SZ = SparkSwzFn<Spark2Swz<kSwz ? W : 0u>>;
+    const uint32_t fb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)fbw;      // LDS byte offset of the wave's buffer
+    if (fb & 255u) __builtin_trap();                                       // (dynamic LDS starts at offset 0, every area before it is a multiple of 256 bytes: never taken)
     const uint32_t g = lane / LPW, xp = lane % LPW;                        // this lane's window of the tile and its column pair (2 xp, 2 xp + 1)
-    // LDS positions of the lane's two base butterflies' outputs (contiguous runs of `base` points)
-    const uint32_t p0 = sw(g * W + (rev4(2 * xp, layers) << GeoT::log_base)), p1 = sw(g * W + (rev4(2 * xp + 1, layers) << GeoT::log_base));
+    // LDS byte addresses of the lane's two base butterflies' outputs (runs of `base` points; piece q at a ^ 16 q)
+    const uint32_t r0 = g * W + (rev4(2 * xp, layers) << GeoT::log_base), r1 = g * W + (rev4(2 * xp + 1, layers) << GeoT::log_base);
+    const uint32_t p0 = fb + ((r0 ^ SZ::delta(r0)) << 3), p1 = fb + ((r1 ^ SZ::delta(r1)) << 3);
     const uint64_t n_tiles = (P.n_windows + GW - 1) / GW;
     SparkWalk walk(n_tiles, wave);
     uint64_t tile = walk.first;
@@ -3596,13 +3591,10 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
 #if !(defined(QD_SPARK_ABL) && (QD_SPARK_ABL & 8))
             if constexpr (base == 16) bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2); else bf8(v, P.root2);
 #endif
-            const uint32_t pb = u == 0 ? p0 : p1;                          // swizzled position of the run's piece 0 ... of ITS piece position f: p0 / p1 are sw(run start)
+            const uint32_t pb = u == 0 ? p0 : p1;                          // byte address of the run's piece 0 in the swizzled layout
 #pragma unroll
-            for (uint32_t q = 0; q < base / 2; ++q) {
-                // piece q (outputs 2 q, 2 q + 1) sits at piece position q ^ f: sw(run start) already has position f in its piece bits, so XOR q in
-                float2 *d = fbw + (pb ^ (kSwz ? (q << 1) : 0u)) + (kSwz ? 0u : 2 * q);
-                d[0] = v[2 * q]; d[1] = v[2 * q + 1];
-            }
+            for (uint32_t q = 0; q < base / 2; ++q)                         // piece q (outputs 2 q, 2 q + 1)
+                *(spark_lds_f4 *)(uintptr_t)(pb ^ (16 * q)) = spark_f4n{v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y};
             __builtin_amdgcn_sched_barrier(0);                              // one column at a time (registers)
         }
         __builtin_amdgcn_sched_barrier(0);                                  // the rows are consumed: their registers take the next tile's rows
@@ -3633,8 +3625,15 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
 #pragma unroll
                 for (uint32_t kk = 0; kk < KB; ++kk) {
                     const uint32_t t = lo + 64 * (k0 + kk), chunk = t >> log_cols, i = t & (cols - 1);
+                    const uint32_t pi = chunk * 4 * cols + i, b0 = fb + ((pi ^ SZ::delta(pi)) << 3);
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) { dp[kk][q] = sw(chunk * 4 * cols + i + q * cols); s[kk][q] = fbw[dp[kk][q]]; }
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        // q cols (index bits log_cols, log_cols + 1, zero in pi): bits below 5 and the XOR value by XOR — inside the low 256 bytes,
+                        // where the aligned base contributes nothing —, bits from 5 up by addition (an instruction offset)
+                        const uint32_t qc = q * cols, lo_q = (qc ^ SZ::delta(qc)) & 31u, hi_q = qc & ~31u;
+                        dp[kk][q] = (b0 ^ (lo_q << 3)) + (hi_q << 3);
+                        s[kk][q] = spark_ld2(dp[kk][q]);
+                    }
                 }
 #pragma unroll
                 for (uint32_t kk = 0; kk < KB; ++kk) {
@@ -3648,7 +3647,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
 #pragma unroll
                     for (uint32_t kk = 0; kk < KB; ++kk)
 #pragma unroll
-                        for (uint32_t q = 0; q < 4; ++q) fbw[dp[kk][q]] = s[kk][q];
+                        for (uint32_t q = 0; q < 4; ++q) spark_st2(dp[kk][q], s[kk][q]);
                 } else {
                     // cols == W / 4: butterfly t of the tile is butterfly i of window t >> log_cols; result k is bin i + k W/4, output (bin + W/2) mod W.
                     // The four |X| of a butterfly take the short form together and test ONE flag for the IEEE form (3e-5 of the bins).
