@@ -61,6 +61,7 @@ def workload_desc(cfg):
 
 DEFAULT_WORKLOAD = "cfg3p"
 BPS = {0: 8, 1: 2, 2: 2, 3: 4}
+FMT_NAMES = {0: "cf32", 1: "cs8", 2: "cu8", 3: "cs16"}
 STREAM_SEED = 0x5EED0002     # ONE seed for the whole stream: the generator is keyed by absolute sample index, not by rank
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E data-sheet peak (MI355X_MICROARCH.md); ~6300 measured copy
 HBM_ACHIEVABLE_GBPS = 6290.0  # what a float4 copy streams on this part (MI355X_MICROARCH.md, chip-level parameters)
@@ -610,16 +611,21 @@ def write_sink_leg(cfg, device, steps=8):
 
 def no_lowpass_leg(device, steps=6):
     """Chains WITHOUT a lowpass (`from F [shift] sparkfft`, README example 1 / BASELINE configs[0]'s chain at scale; informational, never
-    `value`): 16 GiB cf32, stride == width, on the wave-local kernels (k_spark / k_spark2).  Every input sample is an FFT input and every
-    sample yields one f32 norm, so the algorithmic bytes are 8 read + 4 written per sample; fractions are of the 8 TB/s data-sheet peak
-    and of the 6.29 TB/s a copy kernel streams."""
+    `value`) on the wave-local kernels (k_spark / k_spark2).  Every input sample is an FFT input and every window position yields W f32
+    norms, so the algorithmic bytes are the stream read once + 4 W per window written; fractions are of the 8 TB/s data-sheet peak and of
+    the 6.29 TB/s a copy kernel streams."""
     import torch
     import quadrs_amd as Q
-    n = 1 << 31
-    slab = synth_slab(torch, 0, 0, n, STREAM_SEED, device)
-    res = {"stream": "16 GiB cf32 @21 Msps, stride == width", "unit": "ms per pass", "shapes": {}}
-    for label, shift, W in (("w128", None, 128), ("shift_w128", 280000, 128), ("w1024", None, 1024)):
-        p = Q.Plan(0, 21_000_000, n, shift_hz=shift, width=W, stride=W)
+    res = {"stream": "16 GiB @21 Msps (cf32: 2^31 samples; cs8: 2^33), stride == width unless the label says otherwise", "unit": "ms per pass", "shapes": {}}
+    slab, slab_fmt = None, None
+    for label, fmt, shift, W, S in (("w128", 0, None, 128, 128), ("shift_w128", 0, 280000, 128, 128), ("w1024", 0, None, 1024, 1024), ("w64", 0, None, 64, 64),
+                                    ("w128_stride64_4GiB", 0, None, 128, 64), ("cs8_w256", 1, None, 256, 256)):
+        n = (1 << 34) // BPS[fmt] if S == W else (1 << 32) // BPS[fmt]       # (overlapping windows: a quarter of the stream, the output is W / S times the input)
+        if slab is None or slab_fmt != fmt or slab.numel() * slab.element_size() != n * BPS[fmt]:
+            del slab
+            torch.cuda.empty_cache()
+            slab, slab_fmt = synth_slab(torch, fmt, 0, n, STREAM_SEED, device), fmt
+        p = Q.Plan(fmt, 21_000_000, n, shift_hz=shift, width=W, stride=S)
         out = torch.empty(p.n_windows, W, dtype=torch.float32, device=device)
         for _ in range(2):
             p.run_device(slab, out)
@@ -631,8 +637,9 @@ def no_lowpass_leg(device, steps=6):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
-        byts = n * 8 + out.numel() * 4
-        res["shapes"][label] = {"chain": f"{'shift 280000 -> ' if shift else ''}sparkfft -width {W}", "ms": ms, "Msamples_per_s": n / (ms * 1e-3) / 1e6,
+        byts = n * BPS[fmt] + out.numel() * 4
+        res["shapes"][label] = {"chain": f"from {FMT_NAMES[fmt]} {'shift 280000 -> ' if shift else ''}sparkfft -width {W}{'' if S == W else f' -stride {S}'}", "samples": n,
+                                "ms": ms, "Msamples_per_s": n / (ms * 1e-3) / 1e6,
                                 "GBps_read_plus_written": byts / (ms * 1e-3) / 1e9, "hbm_frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "frac_of_achievable": byts / (ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS, "kernel": p.kernel_name(),
                                 "kernel_kind": int(p.info.kernel_kind), "kernel_flags": int(p.info.kernel_flags), "outputs_finite": bool(torch.isfinite(out).all().item())}
