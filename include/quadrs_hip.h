@@ -161,7 +161,7 @@ typedef struct {
     uint32_t kernel_flags;    /* variant bits of the main kernel (0 for the generic kernels): 4 packed lane-per-output FIR, 8 row-aligned
                                  phase 1, 32 straight-line shared FIR, 64 deferred FFT, 128 packed two-output FIR, 256 non-temporal stream loads (65536: only rows no other tile reads), 8192 half-window tiles, 16384 fused FIR (QD_MODE_FAST),
                                  32768 three-stage kernel (producer / FIR / FFT waves on consecutive tiles), 131072 its streaming form (runs of tiles, state carried in LDS), 262144 the streaming kernel as the write sink (QD_EPI_CF32_BLOCKS: producers + FIR waves, no FFT stage),
-                                 524288 the wave-local kernel of chains WITHOUT a lowpass (stride == width: one wave per tile, no workgroup barriers), 1048576 its form with the base butterflies out of the row registers (cf32, W = 128 ... 1024; plan-time builds);
+                                 524288 the wave-local kernel of chains WITHOUT a lowpass (stride == width: one wave per tile, no workgroup barriers), 1048576 its form with the base butterflies out of the row registers (W = 128 ... 1024; plan-time builds), 2097152 overlapping windows of 2 ... 8 points, a window per lane (plan-time builds);
                                  chosen from the chain's geometry at plan time (built-in kernels: the same predicates, fixed at build time) */
     uint32_t _reserved;
 } qd_plan_info;

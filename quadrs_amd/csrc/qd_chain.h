@@ -3702,4 +3702,126 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
 }
 
 
+// ---------------------------------------------------------------- k_spark0: overlapping windows of 2 ... 8 points straight out of registers (FLAGS bits 19 + 21)
+//
+// `from F sparkfft -width 4 -stride 2` — README example 1 and BASELINE configs[0]'s chain — at scale: the transform of such a window is
+// ONE base butterfly (rustfft's Radix4 with no radix-4 layer: natural order in, natural order out), so a LANE owns a window from load to
+// store: W BPS contiguous bytes at byte w S BPS of the stream (neighbouring lanes overlap; the coalescer and L1 serve that, HBM is read
+// once), unpack, butterfly, |X| with the fftshift as a register renaming, and W norms (or glyph bytes, or the bucket digit) stored as one
+// contiguous piece per lane — 64 lanes x 16 bytes = one 1-KiB store instruction for W = 4.  No LDS, no barrier; the next tile's loads go
+// into the registers the unpack has just vacated.  Interleaved launches of k_spark (the stride dividing the width) read the stream W / S
+// times and write rows W / S apart — half-filled store instructions: 2^28 cf32 samples at W = 4 / S = 2 took 2.42 ms there.
+constexpr uint32_t kGeoSparkDirect = 2097152;   // FLAGS bit 21
+
+template <int FMT, class GeoT, int LB, int EPI /* the plan's qd_epilogue */>
+__global__ __launch_bounds__(kThreads, LB) void k_spark0(const ChainParams P) {
+    using FT = FmtTraits<FMT>;
+    constexpr uint32_t W = GeoT::W, S = GeoT::S, BPS = FT::BPS, ND = W * BPS / 4;       // dwords per window
+    static_assert(GeoT::kFixed && W >= 2 && W <= 16 && S >= 1 && S <= W && GeoT::D == 1 && GeoT::T == 0 && (W * BPS) % 4 == 0 && (S * BPS) % 4 == 0,
+                  "k_spark0: one base butterfly per window, dword-aligned windows");
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t n_tiles = (P.n_windows + 63) / 64;                      // a tile: 64 windows, one per lane
+    SparkWalk walk(n_tiles, wave);
+    uint64_t tile = walk.first;
+    const uint64_t n_waves = walk.stride, tile_end = walk.end;
+    if (tile >= tile_end) return;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    auto rsrc_of = [&](uint64_t t) {
+        const uint64_t ns = (P.first_window + t * 64) * S, end = P.src_first + P.src_count;
+        const uint64_t left = ns < end ? (end - ns) * BPS : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src) + (ns - P.src_first) * BPS, 0,
+                                                 left > 0xffffffffull ? 0xffffffffu : (uint32_t)left, 0x00020000);
+    };
+    const uint32_t voff = lane * S * BPS;
+    uint32_t raw[ND];
+    auto load_window = [&](const decltype(rsrc_of(0)) &rsrc) {
+#pragma unroll
+        for (uint32_t d = 0; d < ND;) {
+            if (ND - d >= 4) {
+                const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(d * 4), 0);
+                raw[d] = w.x; raw[d + 1] = w.y; raw[d + 2] = w.z; raw[d + 3] = w.w; d += 4;
+            } else if (ND - d >= 2) {
+                const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)(d * 4), 0);
+                raw[d] = w.x; raw[d + 1] = w.y; d += 2;
+            } else { raw[d] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(d * 4), 0); d += 1; }
+        }
+    };
+    auto sample = [&](uint32_t k) -> float2 {                              // src/lib.rs:241-255
+        if constexpr (FMT == 0) return make_float2(__uint_as_float(raw[2 * k]), __uint_as_float(raw[2 * k + 1]));
+        else if constexpr (FMT == 1) { const uint32_t a = raw[k / 2] ^ 0x80808080u; return make_float2(unpack_cs8_at(a, 2 * (k & 1)), unpack_cs8_at(a, 2 * (k & 1) + 1)); }
+        else if constexpr (FMT == 2) return make_float2(unpack_cu8_at(raw[k / 2], 2 * (k & 1)), unpack_cu8_at(raw[k / 2], 2 * (k & 1) + 1));
+        else return make_float2(unpack_cs16(raw[k] & 0xffffu), unpack_cs16(raw[k] >> 16));
+    };
+    constexpr uint32_t OBW = EPI == 0 ? 4u * W : (EPI == 1 ? W : 1u);     // output bytes per window
+    constexpr uint32_t NST = EPI == 0 ? (W >= 4 ? W / 4 : 1u) : 1u;        // store instructions per tile
+    load_window(rsrc_of(tile));
+    {
+        // the loop's entry edge issues as many (dropped) stores as a tile does: the waits for the prefetched windows stay counted (see k_spark2)
+        const auto none = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out), 0, 0, 0x00020000);
+#pragma unroll
+        for (uint32_t q = 0; q < NST; ++q) __builtin_amdgcn_raw_buffer_store_b32(0u, none, (int)(lane * 4 + q * 256), 0, 2);
+    }
+    while (true) {
+        const uint64_t tile_n = tile + n_waves;
+        const uint64_t w0 = P.first_window + tile * 64, left_w = P.first_window + P.n_windows - w0;
+        const uint32_t g_cnt = left_w < 64 ? (uint32_t)left_w : 64u;
+        const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * OBW, 0, g_cnt * OBW, 0x00020000);
+        float2 v[W];
+#pragma unroll
+        for (uint32_t k = 0; k < W; ++k) v[k] = sample(k);
+        __builtin_amdgcn_sched_barrier(0);                                  // the window is unpacked: its registers take the next tile's
+        load_window(rsrc_of(tile_n < tile_end ? tile_n : tile));            // (last tile of this wave: harmless re-loads)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (W == 16) bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2);
+        else if constexpr (W == 8) bf8(v, P.root2);
+        else if constexpr (W == 4) bf4(v[0], v[1], v[2], v[3]);
+        else bf2(v[0], v[1]);
+        float nm[W];                                                        // nm[o] = |X[(o + W/2) mod W]| (src/fft.rs:48-52; bucket sink: |X[o]|)
+#pragma unroll
+        for (uint32_t o0 = 0; o0 < W; o0 += 4) {
+            constexpr uint32_t NQ = W >= 4 ? 4 : W;
+            bool sl[NQ];
+            bool any = false;
+            constexpr uint32_t kShift = EPI == 2 ? 0u : W / 2;             // (freq_levels sums the bins in their own order: src/fft.rs:86-97)
+#pragma unroll
+            for (uint32_t q = 0; q < NQ; ++q) { const float2 x = v[(o0 + q) ^ kShift]; nm[o0 + q] = norm_fast(x.x, x.y, sl[q]); any |= sl[q]; }
+            if (__builtin_expect(any, 0)) {
+#pragma unroll
+                for (uint32_t q = 0; q < NQ; ++q) if (sl[q]) { const float2 x = v[(o0 + q) ^ kShift]; nm[o0 + q] = norm_ieee(x.x, x.y); }
+            }
+        }
+        if constexpr (EPI == 0) {
+            if constexpr (W >= 4) {
+#pragma unroll
+                for (uint32_t q = 0; q < W / 4; ++q) {
+                    const v4u_t o = {__float_as_uint(nm[4 * q]), __float_as_uint(nm[4 * q + 1]), __float_as_uint(nm[4 * q + 2]), __float_as_uint(nm[4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)(lane * OBW), (int)(q * 16), 2);
+                }
+            } else {
+                const v2u_t o = {__float_as_uint(nm[0]), __float_as_uint(nm[1])};
+                __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, (int)(lane * OBW), 0, 2);
+            }
+        } else if constexpr (EPI == 1) {
+            uint32_t pk[(W + 3) / 4] = {};
+#pragma unroll
+            for (uint32_t o = 0; o < W; ++o) pk[o / 4] |= (uint32_t)glyph_code(nm[o], P.rmin, P.rmax, P.gstep) << (8 * (o & 3));
+            if constexpr (W == 16) { const v4u_t o = {pk[0], pk[1], pk[2], pk[3]}; __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)(lane * OBW), 0, 2); }
+            else if constexpr (W == 8) { const v2u_t o = {pk[0], pk[1]}; __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, (int)(lane * OBW), 0, 2); }
+            else if constexpr (W == 4) __builtin_amdgcn_raw_buffer_store_b32(pk[0], orsrc, (int)(lane * OBW), 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pk[0], orsrc, (int)(lane * OBW), 0, 2);
+        } else {
+            float first = 0.f, second = 0.f;                                // src/fft.rs:95-97: the halves summed in order
+#pragma unroll
+            for (uint32_t k = 0; k < W / 2; ++k) first = first + nm[k];
+#pragma unroll
+            for (uint32_t k = W / 2; k < W; ++k) second = second + nm[k];
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(first < second ? 0 : 1), orsrc, (int)lane, 0, 2);
+        }
+        if (tile_n >= tile_end) break;
+        tile = tile_n;
+    }
+}
+
+
 }  // namespace qd

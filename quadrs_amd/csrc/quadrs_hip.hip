@@ -472,6 +472,10 @@ hipFunction_t jit_chain_kernel(const JitKey &k, std::string *why, bool may_compi
         return nullptr;
     }
     char name[512];
+    if ((k.flags & kGeoSpark) && (k.flags & kGeoSparkDirect))   // ... overlapping windows of 2 ... 8 points, a window per lane
+        snprintf(name, sizeof name, "qd::k_spark0<%d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.W,
+                 k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.lb, k.epi);
+    else
     if ((k.flags & kGeoSpark) && (k.flags & kGeoSparkReg))      // ... with the first FFT pass out of registers (cf32, W = 128 ... 1024)
         snprintf(name, sizeof name, "qd::k_spark2<%d, %d, qd::FixedGeo<%u, %u, %u, %u, %u, %u, %u, %u, %u, %u>, %d, %d>", k.fmt, k.nco, k.W,
                  k.S, k.D, k.T, k.G, k.firb, k.firr, k.pad, k.batch, k.flags, k.lb, k.epi);
@@ -914,6 +918,7 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     bool fast_misaligned = (p->kflags & (kGeoFastP1 | kGeoPipe3)) && (p->jit_fn || p->fixed) && ((first_window * p->S * p->D) % ((uint64_t)p->nt * spl)) != 0;
     // the wave-local kernel: tiles start on NCO rows when the chain shifts, on load vectors otherwise; irregular rows (take_fft) never run on it
     if (p->spark) fast_misaligned = phases_unaligned || p->row_offsets_d != nullptr || ((first_window * p->S) % (p->has_shift ? (uint64_t)kSparkRow : (uint64_t)spl)) != 0;
+    if (p->spark && (p->kflags & kGeoSparkDirect) && p->jit_fn) fast_misaligned = p->row_offsets_d != nullptr;      // a window per lane: any window start (S BPS is a multiple of 4)
     if (vec_ok && !fast_misaligned) {
         // windows [first_window, first_window + n_aligned): need-end rounded up to a vector fits in the slab
         const uint64_t step = (uint64_t)p->S * p->D, rpw = (uint64_t)p->W * p->D + p->T;
@@ -1111,15 +1116,19 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     // as plan-time builds only:
     //   * W = 128 ... 1024, any stride: ONE launch of k_spark2 built for the stride — every window's rows are loaded for it, the overlap
     //     comes out of the caches;
-    //   * smaller widths whose stride divides them: the windows phi, phi + R, phi + 2R ... (R = W / S) lie side by side in the stream
+    //   * W = 2 ... 8, any stride: k_spark0 — a lane owns a window from load to store (one base butterfly), no LDS;
+    //   * the widths between whose stride divides them: the windows phi, phi + R, phi + 2R ... (R = W / S) lie side by side in the stream
     //     shifted by phi * S samples, so the chain is R launches of k_spark, each writing every R-th output row (the row stride lives in
     //     its lean epilogue: norms and glyph sinks).
     // Everything else stays on k_chain.
     if (!p->has_fir && !p->has_shift && p->S < p->W && p->W <= kSparkMaxW && d.epilogue != QD_EPI_CF32_BLOCKS &&
-        policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME && ((uint64_t)p->S * bps_of(d.format)) % 4 == 0 && p->W >= (uint32_t)spl_of(d.format)) {
+        policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME && ((uint64_t)p->S * bps_of(d.format)) % 4 == 0) {
+        // k_spark0: a window per lane, no LDS.  (W = 16 builds and is bit-exact too, but a lane's 64-byte output piece makes quarter-filled
+        // store instructions: 2^28 cf32 samples at S = 4 took 5.2 ms against 2.6 for the interleaved launches)
+        const bool direct = p->W >= 2 && p->W <= 8 && ((uint64_t)p->W * bps_of(d.format)) % 4 == 0;
         const bool one_launch = p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024;
-        const bool phases = p->W % p->S == 0 && p->W / p->S <= 32 && (d.epilogue == QD_EPI_NORMS_F32 || d.epilogue == QD_EPI_GLYPH_U8);
-        if (one_launch || phases) { p->spark = true; p->spark_ov = true; p->spark_R = phases ? p->W / p->S : 1; }
+        const bool phases = p->W % p->S == 0 && p->W / p->S <= 32 && (d.epilogue == QD_EPI_NORMS_F32 || d.epilogue == QD_EPI_GLYPH_U8) && p->W >= (uint32_t)spl_of(d.format);
+        if (direct || one_launch || phases) { p->spark = true; p->spark_ov = true; p->spark_R = phases ? p->W / p->S : 1; }
     }
     uint32_t tune[8] = {0, 0, 1, 8, 4, 1, 1, 0};
     uint32_t hint_flags = 0;
@@ -1326,6 +1335,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
                 p->spark_R = 0;
             }
         }
+        if (p->spark_ov && !p->jit_fn && jit_ok && p->W >= 2 && p->W <= 8 && ((uint64_t)p->W * bps_of(d.format)) % 4 == 0) {
+            JitKey k{d.format, 0, 0, 0, 1, 4, kThreads, p->W, p->S, 1, 0, 64, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkDirect, 0ull, d.epilogue};
+            if (hipFunction_t f = jit_chain_kernel(k, &p->jit_note, may_compile)) {
+                p->jit_fn = f; G = 64; kflags |= kGeoSparkDirect; p->spark_lb = 4; p->spark_R = 0;
+            }
+        }
         if (p->spark_ov && !p->jit_fn) {
             // interleaved launches need a plan-time build (k_spark with the sink as a template argument); none to be had: back to k_chain
             const int lbj = 4;
@@ -1367,6 +1382,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     if (!(kflags & (kGeoHalfTile | kGeoPipe3))) p->geo.lds_main = p->geo.lds_bytes;
     if (p->spark) p->geo.lds_main = ((size_t)(p->W < 32 ? 32 : p->W) + 4 * (size_t)p->spark_ts) * 8 +     // twiddles | four waves' transform buffers (k_spark)
                                     ((((kflags & kGeoSparkReg) && p->has_shift) || p->spark_jt_lds) ? (size_t)kSparkRow * 16 : 0);   // plan-time builds with a shift: + the NCO lane table
+    if (kflags & kGeoSparkDirect) p->geo.lds_main = 16;                 // k_spark0 uses no LDS (a token size: 0 means "the generic layout's")
     p->geo.lds_raw_elems = raw_elems;
     p->geo.Dp = p->D + ((p->D % 2 == 0) ? 1 : 0);
     if ((uint64_t)raw_elems * p->D >= (1ull << 32)) return fail(QD_ERR_UNSUPPORTED, "tile too large");
@@ -1684,7 +1700,8 @@ int qd_plan_kernel_name(const qd_plan *p, char *buf, size_t cap) {
     if (p->jit_fn || p->fixed)
         snprintf(geo, sizeof geo, "FixedGeo<%u, %u, %u, %u, %u, ..., %u>", p->W, p->S, p->D, p->T, p->geo.G, p->kflags);
     else snprintf(geo, sizeof geo, "DynGeo");
-    const char *kn = (p->kflags & kGeoSparkReg) && p->jit_fn ? "qd::k_spark2"
+    const char *kn = (p->kflags & kGeoSparkDirect) && p->jit_fn ? "qd::k_spark0"
+                   : (p->kflags & kGeoSparkReg) && p->jit_fn ? "qd::k_spark2"
                    : p->spark ? "qd::k_spark"
                    : ((p->kflags & kGeoPipe3) && (p->kflags & kGeoStream) && (p->jit_fn || p->fixed)) ? "qd::k_chain_pipe3s"
                    : ((p->kflags & kGeoPipe3) && (p->jit_fn || p->fixed)) ? "qd::k_chain_pipe3"

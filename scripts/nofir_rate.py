@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 only_overlap = len(sys.argv) > 2 and sys.argv[2] == "overlap"
 for fmt, shift, W, S in ((0, None, 128, 128), (0, 280000, 128, 128), (0, None, 1024, 1024), (0, 280000, 64, 16), (1, 280000, 256, 256), (0, None, 4, 2), (0, 280000, 16, 16), (0, 280000, 64, 64), (0, 280000, 256, 256), (3, 280000, 512, 512),
                         (0, None, 64, 64), (0, None, 16, 16), (0, 280000, 32, 32), (0, None, 8, 8), (1, None, 64, 64), (1, 280000, 16, 16), (3, None, 32, 32),
-                        (0, None, 64, 16), (0, None, 128, 64), (0, None, 1024, 256), (1, None, 64, 16), (3, None, 256, 128)):
+                        (0, None, 16, 4), (0, None, 8, 4), (0, None, 8, 2), (0, None, 16, 8), (1, None, 4, 2), (1, None, 16, 4), (3, None, 8, 4), (0, None, 64, 16), (0, None, 128, 64), (0, None, 1024, 256), (1, None, 64, 16), (3, None, 256, 128)):
     if only_overlap and (S == W or shift is not None):
         continue
     n = 1 << (log2 + (2 if fmt == 1 else 0) - (3 if S < W else 0))

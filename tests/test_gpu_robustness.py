@@ -824,26 +824,28 @@ def test_overlapping_windows_without_lowpass_as_interleaved_launches(engine, ora
     bps = {0: 8, 1: 2, 3: 4}[fmt]
     spl = {0: 2, 1: 4, 3: 4}[fmt]
     sr = 21_000_000
-    for W, S in ((4, 2), (8, 4), (16, 4), (64, 16), (64, 24), (128, 64), (128, 48), (256, 32), (256, 200), (512, 256), (1024, 512), (1024, 32)):
+    for W, S in ((2, 1), (4, 2), (8, 4), (8, 6), (16, 4), (16, 2), (32, 8), (64, 16), (64, 24), (128, 64), (128, 48), (256, 32), (256, 200), (512, 256), (1024, 512), (1024, 32)):
         n = 9 * 1024 + 3 * W + 5
         data = _synth_bytes(fmt, n, 77 * fmt + W + S)
         ch = oracle.Chain.from_bytes(data, fmt, sr)
         ref, _ = ch.spark_fft(W, S)
         for epi, rng_ in ((engine.EPI_NORMS_F32, None), (engine.EPI_GLYPH_U8, (0.01, 0.5) if fmt == 0 else (0.3, 30.0)), (engine.EPI_BUCKET2_U8, None)):
-            if epi == engine.EPI_BUCKET2_U8 and W not in (64, 128, 1024):
+            if epi == engine.EPI_BUCKET2_U8 and W not in (4, 16, 64, 128, 1024):
                 continue
             kw = dict(width=W, stride=S, epilogue=epi, rng=rng_)
             j = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_SPECIALISE, **kw)
             g = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_GENERIC, **kw)
-            # W >= 128: one launch at any stride and sink; below: interleaved launches when the stride divides the width (norms / glyphs)
-            expect_phases = W >= spl and (S * bps) % 4 == 0 and (W >= 128 or (W % S == 0 and epi != engine.EPI_BUCKET2_U8))
+            # W <= 8: a window per lane (k_spark0), W >= 128: one launch of k_spark2, both at any stride and sink; between:
+            # interleaved launches of k_spark when the stride divides the width (norms / glyphs)
+            expect_phases = (S * bps) % 4 == 0 and (W <= 8 or W >= 128 or (W >= spl and W % S == 0 and epi != engine.EPI_BUCKET2_U8))
             assert bool(j.info.kernel_flags & 524288) == expect_phases, (fmt, W, S, j.info.kernel_flags)
             if expect_phases:
                 assert j.info.kernel_kind == 2
                 # W = 128 ... 1024: ONE launch of the register-first-pass kernel built for the stride (the overlap comes out of the caches);
                 # below: W / S interleaved launches, any window range (ranges on multiples of tile_windows keep the fast path)
                 assert bool(j.info.kernel_flags & 1048576) == (W in (128, 256, 512, 1024))
-                assert j.info.tile_windows == (max(1, spl // S) if W < 128 else {128: 8, 256: 8, 512: 2, 1024: 2}[W])
+                assert bool(j.info.kernel_flags & 2097152) == (W <= 8)
+                assert j.info.tile_windows == (64 if W <= 8 else max(1, spl // S) if W < 128 else {128: 8, 256: 8, 512: 2, 1024: 2}[W])
             else:
                 assert not (j.info.kernel_flags & 524288)
             a, b = j.run_host(data), g.run_host(data)
