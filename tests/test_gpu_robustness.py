@@ -874,6 +874,18 @@ def test_overlapping_windows_without_lowpass_as_interleaved_launches(engine, ora
 
 
 @pytest.mark.gpu
+def test_random_lowpass_free_shapes(engine, oracle):
+    """Random `from F [shift] sparkfft -width W -stride S` chains (every format, W = 1 ... 1024, strides up to 2 W, three sinks, whole
+    streams and random window sub-ranges): the plan-time builds of the wave-local family against the generic chain kernel and the oracle."""
+    import quadrs_amd as Q
+    from util import fuzz_nofir_shapes
+    stats = []
+    checked, bad = fuzz_nofir_shapes(Q, 40, 20261005, oracle=oracle, stats=stats)
+    assert checked >= 30 and not bad, bad
+    assert sum(1 for k, f in stats if f & 524288) >= 10      # the family under test was actually chosen
+
+
+@pytest.mark.gpu
 def test_wave_local_kernel_many_tiles(engine, oracle):
     """More tiles than resident waves (grid-stride walk, prefetch of the next tile, the last wave's short run): 2^24 cf32 samples,
     W = 128 with and without a shift, against the generic kernel bit for bit and against the oracle on sampled windows."""

@@ -155,6 +155,85 @@ def fuzz_chain_shapes(Q, n_shapes, seed, log=None, oracle=None, variants_only=Fa
     return checked, bad
 
 
+def fuzz_nofir_shapes(Q, n_shapes, seed, log=None, oracle=None, stats=None):
+    """Random chains WITHOUT a lowpass (`from F [shift] sparkfft -width W -stride S`): the plan-time builds of the wave-local kernel family
+    (k_spark swizzled, k_spark2, k_spark0, interleaved launches; QD_KERNEL_SPECIALISE) against the generic chain kernel, bit for bit
+    without a shift and where the NCO row grids agree (cf32), within the NCO's tolerance otherwise — whole streams and a random window
+    sub-range each; with `oracle` (tests only) also against the CPU oracle: bit-exact without a shift, 1 ulp of the window maximum with.
+    Returns (checked, mismatching descriptions)."""
+    from quadrs_amd import _ffi
+    rng = np.random.default_rng(seed)
+    checked, bad = 0, []
+    for _ in range(n_shapes):
+        fmt = int(rng.integers(0, 4))
+        W = 1 << int(rng.integers(0, 11))
+        S = int(rng.choice([W, W, max(1, W // 2), max(1, W // 4), int(rng.integers(1, W + 1)), int(rng.integers(1, 2 * W + 1))]))
+        shift = None if rng.random() < 0.55 else int(rng.integers(-3_000_000, 3_000_000))
+        epi = int(rng.choice([0, 0, 1, 2]))
+        if epi == 2 and W < 2:
+            epi = 0
+        bps = {0: 8, 1: 2, 2: 2, 3: 4}[fmt]
+        N = int(rng.integers(2, 600)) * S + W + int(rng.integers(0, max(2, S)))
+        N = min(N, 300_000)
+        data = rng.integers(0, 256, N * bps, dtype=np.uint8)
+        if fmt == 0:
+            data = (rng.standard_normal((N, 2)).astype(np.float32) * 0.05).view(np.uint8).reshape(-1)
+        raw = data.tobytes()
+        kw = dict(shift_hz=shift, width=W, stride=S, epilogue=epi, rng=(0.01, 0.5) if fmt == 0 else (0.3, 30.0))
+        desc = f"fmt={fmt} W={W} S={S} shift={shift} N={N} epi={epi}"
+        try:
+            j = Q.Plan(fmt, 21_000_000, N, kernel_policy=_ffi.KERNEL_SPECIALISE, **kw)
+            g = Q.Plan(fmt, 21_000_000, N, kernel_policy=_ffi.KERNEL_GENERIC, **kw)
+        except Q.QuadrsError as e:
+            if log:
+                log("skip " + desc + ": " + str(e)[:80])
+            continue
+        a, b = j.run_host(raw), g.run_host(raw)
+        desc += f" kind={j.info.kernel_kind} flags={j.info.kernel_flags}"
+        if stats is not None:
+            stats.append((int(j.info.kernel_kind), int(j.info.kernel_flags)))
+
+        def same(x, y):
+            if x.shape != y.shape:
+                return False
+            if shift is None or fmt == 0 or x.dtype != np.float32:
+                # (8-bit formats and cs16 with a shift: the wave-local kernels' NCO rows are 512 samples, the generic kernel's 1024 —
+                # two tilings of the same scheme, DESIGN section 4; sinks that quantise are compared through the norms' tolerance below)
+                return x.tobytes() == y.tobytes() if (shift is None or fmt == 0) else True
+            scale = ulp_of(np.maximum(np.abs(y).max(axis=-1, keepdims=True), 1e-30)).astype(np.float64)
+            return bool((np.abs(x.astype(np.float64) - y.astype(np.float64)) <= scale).all())
+        ok = same(a, b)
+        nw = j.n_windows
+        if ok and nw > 2:
+            w0 = int(rng.integers(1, nw))
+            cnt = int(rng.integers(1, nw - w0 + 1))
+            first, count = j.src_range(w0, cnt)
+            sub = j.run_host(raw[first * bps:(first + count) * bps], w0, cnt, src_first=first)
+            ok = sub.tobytes() == a[w0:w0 + cnt].tobytes()
+            if not ok:
+                desc += f" SUB-RANGE w0={w0} cnt={cnt}"
+        if ok and epi == 0 and oracle is not None and nw > 0:
+            ch = oracle.Chain.from_bytes(raw, fmt, 21_000_000)
+            if shift is not None:
+                ch = ch.shift(shift)
+            ref, _ = ch.spark_fft(W, S, max_windows=32)
+            got = a[:ref.shape[0]]
+            if shift is None:
+                ok = bits_equal(ref, got)
+            else:
+                scale = ulp_of(np.maximum(np.abs(ref).max(axis=-1, keepdims=True), 1e-30)).astype(np.float64)
+                ok = bool((np.abs(ref.astype(np.float64) - got.astype(np.float64)) <= scale).all())
+            if not ok:
+                desc += " ORACLE"
+        j.close(); g.close()
+        if log:
+            log(("ok  " if ok else "BAD ") + desc)
+        checked += 1
+        if not ok:
+            bad.append(desc)
+    return checked, bad
+
+
 def full_size_census(Q, O, bench, name):
     """EVERY window of BASELINE workload `name` at its full size: HIP chain kernel against the CPU oracle in its cheapest exact
     form (FIR at the decimated positions only, same products, same order) on all host cores, same input bytes, absolute sample
