@@ -79,7 +79,8 @@ def valu_ops_per_sample(cfg, nco_order):
     one packed multiply and one packed add per tap (re and im, separately rounded); NCO: 9 (first order)
     / 12 (second order) f64 ops + 2 f64->f32 converts, complex multiply 3 packed ops; FFT ~5 W log2 W flops per window; |X| per
     bin: the short exact form (see below); unpack per sample (two components):
-    8-bit ~10 f32 ops (convert, bias, multiply by the reciprocal, residual, correction), cs16 12."""
+    cs8 two converts (signed byte -> f32 in one SDWA instruction) + 2 packed ops (the two-operation exact division of qd_device.h on both
+    components), cu8 / cs16 one more packed op (the bias subtraction).  Round 3: 10 / 12 scalar operations."""
     fc, D, T = cfg["lp"] if cfg["lp"] else (0, 1, 0)
     W, S = cfg["W"], cfg["S"]
     f32 = 5.0 * W * math.log2(W) / (S * D)
@@ -92,7 +93,8 @@ def valu_ops_per_sample(cfg, nco_order):
     if cfg["shift"] is not None:
         pk += 3.0
         f64 += (12.0 if nco_order == 2 else 9.0) + 2.0
-    f32 += {0: 0.0, 1: 10.0, 2: 10.0, 3: 12.0}[cfg["fmt"]]
+    f32 += {0: 0.0, 1: 2.0, 2: 2.0, 3: 2.0}[cfg["fmt"]]
+    pk += {0: 0.0, 1: 2.0, 2: 3.0, 3: 3.0}[cfg["fmt"]]
     return f32, f64, pk
 
 

@@ -93,23 +93,27 @@ __device__ __forceinline__ float norm_ref(float2 v) {
 
 // ---------------------------------------------------------------- unpack (src/lib.rs:241-255)
 
-// one IEEE f32 division (+ one IEEE subtraction); hipcc's default f32 '/' is correctly rounded
-// Correctly rounded f / d for the small integers the sample formats produce, without the division sequence: q = f * RN(1/d),
-// then one residual step, e = fma(-q, d, f) (exact), q + e * RN(1/d) rounded once.  Verified against the IEEE quotient for
-// EVERY input of the three formats (256 / 256 / 65536 values; tests/test_oracle_golden.py restates the check on the CPU).
-__device__ __forceinline__ float div_small(float f, float d, float rd) {
-    const float q = f * rd;
-    const float e = __builtin_fmaf(-q, d, f);
-    return __builtin_fmaf(e, rd, q);
-}
-// one 8-bit pair component out of a packed word: the byte as f32 (v_cvt_f32_ubyteN), no table
-__device__ __forceinline__ float unpack_cs8_at(uint32_t w_flipped /* word ^ 0x80808080 */, int k) {
-    const float f = (float)((w_flipped >> (8 * k)) & 0xffu) - 128.0f;        // (b as i8) as f32, exact
-    return div_small(f, 127.0f, 1.0f / 127.0f);
+// Correctly rounded f / d for the small integers the sample formats produce, without the division sequence and in TWO operations:
+// 1 / d = hi + lo (hi = RN(1/d), lo = RN(1/d - hi): 1/d to 2^-48), q = fma(f, hi, RN(f * lo)).  f hi + RN(f lo) is the quotient to
+// 2^-47 relative and the fma rounds it ONCE; no quotient of these integers lies that close to an f32 rounding boundary unless it is
+// exact (|f 2^k - d m| >= 1 for integers).  Verified against the IEEE quotient for EVERY input of the three formats (256 / 256 /
+// 65536 values; tests/test_unpack_division.py restates the two operations in rational arithmetic; the GPU suite runs every code
+// through the kernels).  Round 4: was q = f RN(1/d) plus a residual step, three operations.
+__device__ __forceinline__ float div_small(float f, float hi, float lo) { return __builtin_fmaf(f, hi, f * lo); }
+constexpr float kInv127Hi = 0x1.020408p-7f, kInv127Lo = 0x1.020408p-35f;
+constexpr float kInv255Hi = 0x1.010102p-8f, kInv255Lo = -0x1.fdfdfep-33f;
+constexpr float kInv65535Hi = 0x1.0001p-16f, kInv65535Lo = 0x1.0001p-48f;
+// one 8-bit pair component out of a packed word: the signed byte as f32 in one instruction (v_cvt_f32_i32 with an SDWA byte select and
+// sign extension), and hipcc pairs the two components of a sample into v_pk_mul_f32 + v_pk_fma_f32: 2 + 2 instructions per sample
+// (round 3: 10)
+__device__ __forceinline__ float unpack_cs8_at(uint32_t w_flipped /* word ^ 0x80808080 (the callers' form; the flip folds away) */, int k) {
+    const uint32_t w = w_flipped ^ 0x80808080u;
+    const float f = (float)(int8_t)(uint8_t)((w >> (8 * k)) & 0xffu);        // (b as i8) as f32, exact
+    return div_small(f, kInv127Hi, kInv127Lo);
 }
 __device__ __forceinline__ float unpack_cu8_at(uint32_t w, int k) {
     const float f = (float)((w >> (8 * k)) & 0xffu);
-    return div_small(f, 255.0f, 1.0f / 255.0f) - 127.5f;
+    return div_small(f, kInv255Hi, kInv255Lo) - 127.5f;
 }
 __device__ __forceinline__ float unpack_cs8(uint32_t b) { return (float)(int8_t)(uint8_t)b / 127.0f; }
 __device__ __forceinline__ float unpack_cu8(uint32_t b) {
@@ -117,7 +121,7 @@ __device__ __forceinline__ float unpack_cu8(uint32_t b) {
     return q - 127.5f;
 }
 __device__ __forceinline__ float unpack_cs16(uint32_t h) {
-    const float q = div_small((float)(int16_t)(uint16_t)h, 65535.0f, 1.0f / 65535.0f);
+    const float q = div_small((float)(int16_t)(uint16_t)h, kInv65535Hi, kInv65535Lo);
     return q - 32767.5f;
 }
 

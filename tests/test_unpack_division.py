@@ -1,7 +1,10 @@
 """The HIP unpack computes `sample / 127.0`, `/ 255.0`, `/ 65535.0` (src/samples.rs:93-127 via the oracle's restatement) without
-a division: q = f * RN(1/d), e = fma(-q, d, f), result = fma(e, RN(1/d), q) (quadrs_amd/csrc/qd_device.h: div_small).  This
-restates that sequence in exact rational arithmetic and checks it against the correctly rounded quotient for EVERY input value of
-the three integer sample formats — the kernel's bit-exactness for cs8 / cu8 / cs16 rests on it."""
+a division: 1/d = hi + lo (hi = RN(1/d), lo = RN(1/d - hi)), result = fma(f, hi, RN(f * lo)) (quadrs_amd/csrc/qd_device.h:
+div_small, with the constants written there as hex floats).  This restates the two operations in exact rational arithmetic and checks
+them against the correctly rounded quotient for EVERY input value of the three integer sample formats — the kernel's bit-exactness for
+cs8 / cu8 / cs16 rests on it — and the header's literal constants against hi and lo."""
+import os
+import re
 import math
 from fractions import Fraction
 
@@ -27,11 +30,24 @@ def rn32(x):
     return s * n * ulp
 
 
+def split(d):
+    hi = rn32(Fraction(1, d))
+    return hi, rn32(Fraction(1, d) - hi)
+
+
 def div_small(f, d):
-    rd = rn32(Fraction(1, d))
-    q = rn32(f * rd)
-    e = rn32(f - q * d)          # fma(-q, d, f): one rounding
-    return rn32(q + e * rd)      # fma(e, rd, q): one rounding
+    hi, lo = split(d)
+    t = rn32(f * lo)             # the multiply: one rounding
+    return rn32(f * hi + t)      # fma(f, hi, t): one rounding
+
+
+def test_header_constants_are_the_split_reciprocals():
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quadrs_amd", "csrc", "qd_device.h")).read()
+    for d in (127, 255, 65535):
+        m = re.search(r"kInv%dHi = (-?0x[0-9a-fp.+-]+)f, kInv%dLo = (-?0x[0-9a-fp.+-]+)f" % (d, d), hdr)
+        assert m, d
+        hi, lo = split(d)
+        assert Fraction(float.fromhex(m.group(1))) == hi and Fraction(float.fromhex(m.group(2))) == lo, (d, m.groups())
 
 
 def test_reciprocal_plus_residual_equals_ieee_division_for_every_sample_value():
