@@ -71,11 +71,12 @@ int bps_of(int fmt) { return fmt == QD_FMT_CF32 ? 8 : (fmt == QD_FMT_CS16 ? 4 : 
 // ------------------------------------------------------------------ small kernels
 
 // Row bases: (cos, sin) of the exact product (row*ROW) * ratio (qd_device.h, NCO), plus nf itself.
-__global__ void k_rowtab(double ratio, uint32_t row_len, uint64_t row0, uint64_t n_rows, RowBase *out) {
+// (n_off: the row grid of a stream that starts n_off samples into the plan's — the interleaved launches of overlapping lowpass-free windows)
+__global__ void k_rowtab(double ratio, uint32_t row_len, uint64_t row0, uint64_t n_rows, uint64_t n_off, RowBase *out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     RowBase rb;
-    rb.nf = (double)((row0 + i) * (uint64_t)row_len);
+    rb.nf = (double)((row0 + i) * (uint64_t)row_len + n_off);
     rb.pad_ = 0.0;
     nco_table_entry(rb.nf, ratio, &rb.c, &rb.s);
     out[i] = rb;
@@ -674,13 +675,14 @@ constexpr size_t kLdsMax = 160 * 1024;
 // rewritten (k_rowtab into the same buffer) or regrown after the stream that last read it has drained.
 struct RowTab {
     RowBase *d = nullptr;
-    uint64_t cap = 0, row0 = 0, rows = 0;
+    uint64_t cap = 0, row0 = 0, rows = 0, off = 0;
     bool used = false;
 };
 // tables one launch context needs: the main kernel's rows and, for plans whose main kernel is not 256 threads wide,
 // rows laid out for the 256-thread per-sample kernel that takes the windows at an unaligned slab end
 struct NcoTabs {
     RowTab main, tail;
+    std::vector<RowTab> phase;               // interleaved launches with a shift: one row grid per launch (offset phi S)
     unsigned long long *work = nullptr;      // the launch context's tile-queue counters (ChainParams::work), zero between launches
     // One launch context = one set of tile-queue counters + row tables, so launches that use it are ORDERED even when they
     // come on different streams: every launch records `done` behind itself, and a launch arriving on another stream waits
@@ -761,9 +763,9 @@ uint64_t out_bytes_per_window(const qd_plan *p) {
     }
 }
 
-int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowTab *t, uint64_t n_lo, uint64_t n_hi, hipStream_t st) {
+int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowTab *t, uint64_t n_lo, uint64_t n_hi, hipStream_t st, uint64_t n_off = 0) {
     const uint64_t r_lo = n_lo / ROW, r_hi = (n_hi + ROW - 1) / ROW + 1;
-    if (t->d && r_lo >= t->row0 && r_hi <= t->row0 + t->rows) { t->used = true; return QD_OK; }
+    if (t->d && t->off == n_off && r_lo >= t->row0 && r_hi <= t->row0 + t->rows) { t->used = true; return QD_OK; }
     // The table is about to be rewritten: whatever read it last must have finished.  launch_chain has already ordered `st` behind
     // the context's previous launch (NcoTabs::done — an event, not the earlier caller's stream handle, which may be destroyed by
     // now), so k_rowtab on `st` runs after every earlier reader.
@@ -774,9 +776,9 @@ int ensure_rowtab_for(qd_plan *p, uint32_t ROW, RowTab *t, uint64_t n_lo, uint64
         HIPCHK(hipMalloc(&t->d, cap * sizeof(RowBase)));
         t->cap = cap;
     }
-    t->row0 = r_lo; t->rows = rows; t->used = true;
+    t->row0 = r_lo; t->rows = rows; t->used = true; t->off = n_off;
     const uint32_t blocks = (uint32_t)((rows + 255) / 256);
-    hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, t->d);
+    hipLaunchKernelGGL(k_rowtab, dim3(blocks), dim3(256), 0, st, p->ratio, ROW, r_lo, rows, n_off, t->d);
     HIPCHK(hipGetLastError());
     return QD_OK;
 }
@@ -811,6 +813,7 @@ int launch_spark_phases(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t s
     P.root2 = (float)std::sqrt(0.5);
     P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
     P.tw = p->tw_d; P.blk_len = p->W; P.lds_dyn = (uint32_t)p->geo.lds_main;
+    P.ratio = p->ratio; P.jtab = p->jtab_d;
     P.out_row_stride = (uint32_t)R;
     if (p->timing) {
         if (!p->ev_made) { HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1)); p->ev_made = true; }
@@ -827,6 +830,14 @@ int launch_spark_phases(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t s
                         (unsigned long long)src_count, (unsigned long long)first_window, (unsigned long long)n_windows);
         P.src = static_cast<const uint8_t *>(src_d) + shift_samples * bps;      // sample n of this launch is sample n + phi S of the stream
         P.src_first = src_first; P.src_count = src_count - shift_samples;
+        if (p->has_shift) {
+            // the NCO row grid of THIS launch's stream: rows of 512 samples that start phi S samples into the plan's (the caller has checked
+            // that the launch's first window sits on it); the lane table does not depend on where a row starts
+            if (tabs->phase.size() < R) tabs->phase.resize(R);
+            const int rc = ensure_rowtab_for(p, kSparkRow, &tabs->phase[phi], k_lo * W, (k_hi + 1) * W + (uint64_t)P.G * W, st, shift_samples);
+            if (rc) return rc;
+            P.rowtab = tabs->phase[phi].d; P.rowtab_row0 = tabs->phase[phi].row0;
+        }
         P.first_window = k_lo; P.n_windows = n_phi; P.out_window0 = k_lo;
         P.out = static_cast<uint8_t *>(out_d) + ((k_lo * R + phi) - out_window0) * obw;
         const uint64_t n_tiles = (n_phi + P.G - 1) / P.G, wgs = (n_tiles + 3) / 4;
@@ -856,7 +867,10 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     bool phases_unaligned = false;
     if (p->spark_R > 1) {
         // interleaved launches of side-by-side windows; a slab that does not start on a load vector goes to the per-sample kernel as ever
-        if (p->jit_fn && !p->row_offsets_d && (reinterpret_cast<uintptr_t>(src_d) % (spl * bps)) == 0 && (src_first % spl) == 0)
+        // (with a shift every launch's first window must sit on its NCO row grid: first_window a multiple of R * 512 / W)
+        const uint64_t row_w = p->W < kSparkRow ? kSparkRow / p->W : 1;
+        if (p->jit_fn && !p->row_offsets_d && (reinterpret_cast<uintptr_t>(src_d) % (spl * bps)) == 0 && (src_first % spl) == 0 &&
+            (!p->has_shift || first_window % ((uint64_t)p->spark_R * row_w) == 0))
             return launch_spark_phases(p, tabs, src_d, src_first, src_count, first_window, n_windows, out_window0, out_d, st);
         phases_unaligned = true;
     }
@@ -1121,12 +1135,12 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
     //     shifted by phi * S samples, so the chain is R launches of k_spark, each writing every R-th output row (the row stride lives in
     //     its lean epilogue: norms and glyph sinks).
     // Everything else stays on k_chain.
-    if (!p->has_fir && !p->has_shift && p->S < p->W && p->W <= kSparkMaxW && d.epilogue != QD_EPI_CF32_BLOCKS &&
+    if (!p->has_fir && p->S < p->W && p->W <= kSparkMaxW && d.epilogue != QD_EPI_CF32_BLOCKS &&
         policy != QD_KERNEL_GENERIC && policy != QD_KERNEL_NO_PLAN_TIME && ((uint64_t)p->S * bps_of(d.format)) % 4 == 0) {
         // k_spark0: a window per lane, no LDS.  (W = 16 builds and is bit-exact too, but a lane's 64-byte output piece makes quarter-filled
         // store instructions: 2^28 cf32 samples at S = 4 took 5.2 ms against 2.6 for the interleaved launches)
-        const bool direct = p->W >= 2 && p->W <= 8 && ((uint64_t)p->W * bps_of(d.format)) % 4 == 0;
-        const bool one_launch = p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024;
+        const bool direct = !p->has_shift && p->W >= 2 && p->W <= 8 && ((uint64_t)p->W * bps_of(d.format)) % 4 == 0;
+        const bool one_launch = !p->has_shift && (p->W == 128 || p->W == 256 || p->W == 512 || p->W == 1024);
         const bool phases = p->W % p->S == 0 && p->W / p->S <= 32 && (d.epilogue == QD_EPI_NORMS_F32 || d.epilogue == QD_EPI_GLYPH_U8) && p->W >= (uint32_t)spl_of(d.format);
         if (direct || one_launch || phases) { p->spark = true; p->spark_ov = true; p->spark_R = phases ? p->W / p->S : 1; }
     }
@@ -1329,13 +1343,15 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             const int lb2 = p->has_shift ? (fbase == 8 ? 3 : 2) : (fbase == 8 ? 4 : 3);
             // (overlapping windows, spark_R: this kernel takes them in ONE launch — every window's rows are loaded for it, the overlap is
             // served by the caches —, so the stride goes into the build and the interleaved launches are off)
-            JitKey k{d.format, p->nco, 0, 0, 1, lb2, kThreads, p->W, p->S, 1, 0, g2, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkReg, 0ull, d.epilogue};
-            if (hipFunction_t f = jit_chain_kernel(k, &p->jit_note, may_compile)) {
-                p->jit_fn = f; p->spark_ts = ts2; G = g2; kflags |= kGeoSparkReg; p->spark_lb = lb2;
-                p->spark_R = 0;
+            // (... without a shift; with one the NCO rows are laid out for whole tiles of side-by-side windows: the S = W build, interleaved)
+            const bool ov_shift = p->spark_ov && p->has_shift;
+            JitKey k{d.format, p->nco, 0, 0, 1, lb2, kThreads, p->W, ov_shift ? p->W : p->S, 1, 0, g2, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkReg, 0ull, d.epilogue};
+            if ((!ov_shift || d.epilogue == QD_EPI_NORMS_F32 || d.epilogue == QD_EPI_GLYPH_U8) && (p->jit_fn = jit_chain_kernel(k, &p->jit_note, may_compile)) != nullptr) {
+                p->spark_ts = ts2; G = g2; kflags |= kGeoSparkReg; p->spark_lb = lb2;
+                if (!ov_shift) p->spark_R = 0;
             }
         }
-        if (p->spark_ov && !p->jit_fn && jit_ok && p->W >= 2 && p->W <= 8 && ((uint64_t)p->W * bps_of(d.format)) % 4 == 0) {
+        if (p->spark_ov && !p->has_shift && !p->jit_fn && jit_ok && p->W >= 2 && p->W <= 8 && ((uint64_t)p->W * bps_of(d.format)) % 4 == 0) {
             JitKey k{d.format, 0, 0, 0, 1, 4, kThreads, p->W, p->S, 1, 0, 64, 8, 1, 0, 1, 1, kGeoSpark | kGeoSparkDirect, 0ull, d.epilogue};
             if (hipFunction_t f = jit_chain_kernel(k, &p->jit_note, may_compile)) {
                 p->jit_fn = f; G = 64; kflags |= kGeoSparkDirect; p->spark_lb = 4; p->spark_R = 0;
@@ -1347,7 +1363,7 @@ static int plan_init(qd_plan *p, const qd_chain_desc &d, uint64_t len, uint64_t 
             JitKey k{d.format, p->nco, 0, (int)(p->spark_ts / (64u * (uint32_t)spl_of(d.format))), 1, lbj, kThreads,
                      p->W, p->W, 1, 0, G, 8, 1, 0, 1, 1, kGeoSpark, 0ull, d.epilogue};
             p->jit_fn = jit_ok && p->spark_R > 1 ? jit_chain_kernel(k, &p->jit_note, may_compile) : nullptr;
-            if (p->jit_fn) p->spark_lb = lbj;
+            if (p->jit_fn) { p->spark_lb = lbj; p->spark_jt_lds = p->has_shift; }
             else {
                 p->spark = false; p->spark_ov = false; p->spark_R = 0; p->spark_ts = 0; kflags = 0; p->nt = kThreads; G = 1;
                 while (G < 64 && (uint64_t)G * p->W < 256 && lds_for(G * 2, p->W, p->S, p->D, T_lds, nullptr, 1, 1, lut8) <= 40 * 1024) G *= 2;
@@ -1619,7 +1635,11 @@ int qd_plan_create_ex(const qd_chain_desc *desc, const qd_plan_options *options,
     const uint64_t step = (uint64_t)(p->blk_len ? p->blk_len : p->S) * p->D, rpw = (uint64_t)(p->blk_len ? p->blk_len : p->W) * p->D + p->T;
     // API windows of the write sink are whole blocks; interleaved launches take any window range, and keep their speed when it starts on a load vector
     uint32_t tile_api = p->blk_len ? 1u : p->geo.G;
-    if (p->spark_R > 1) { tile_api = (uint32_t)spl_of(d.format); while (tile_api > 1 && ((uint64_t)(tile_api / 2) * p->S) % spl_of(d.format) == 0) tile_api /= 2; p->phase_unit = tile_api; }
+    if (p->spark_R > 1) {
+        tile_api = (uint32_t)spl_of(d.format); while (tile_api > 1 && ((uint64_t)(tile_api / 2) * p->S) % spl_of(d.format) == 0) tile_api /= 2;
+        if (p->has_shift) tile_api = p->spark_R * (p->W < kSparkRow ? kSparkRow / p->W : 1u);      // ... and with a shift on the launches' NCO row grids
+        p->phase_unit = tile_api;
+    }
     partition_windows(p->n_windows, n_shards, step, rpw, tile_api, &p->shard_info);
     for (uint32_t g = 0; g < n_shards; ++g) p->shard_info[g].device = n_shards > 1 ? opt.shard_device[g] : p->device;
     if (n_shards > 1) {
@@ -1655,7 +1675,7 @@ int qd_plan_destroy(qd_plan *p) {
     if (p->tw_d) (void)hipFree(p->tw_d);
     if (p->jtab_d) (void)hipFree(p->jtab_d);
     if (p->jtab256_d) (void)hipFree(p->jtab256_d);
-    for (NcoTabs *t : {&p->tabs_dev, &p->tabs_slot[0], &p->tabs_slot[1]}) { free_rowtab(&t->main); free_rowtab(&t->tail); if (t->work) (void)hipFree(t->work); t->work = nullptr; if (t->done) (void)hipEventDestroy(t->done); t->done = nullptr; t->launched = false; }
+    for (NcoTabs *t : {&p->tabs_dev, &p->tabs_slot[0], &p->tabs_slot[1]}) { free_rowtab(&t->main); free_rowtab(&t->tail); for (RowTab &q : t->phase) free_rowtab(&q); t->phase.clear(); if (t->work) (void)hipFree(t->work); t->work = nullptr; if (t->done) (void)hipEventDestroy(t->done); t->done = nullptr; t->launched = false; }
     if (p->ev_made) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
     delete p;
     return QD_OK;
@@ -2337,7 +2357,7 @@ int qd_shift(qd_c32 *buf, size_t n, uint64_t abs_off, double ratio, int mem) {
     void *rt = nullptr, *jt = nullptr;
     int rc = ws.get(2, rows * sizeof(RowBase), &rt); if (rc) return rc;
     rc = ws.get(3, ROW * sizeof(double2), &jt); if (rc) return rc;
-    hipLaunchKernelGGL(k_rowtab, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, st, ratio, ROW, r0, rows, static_cast<RowBase *>(rt));
+    hipLaunchKernelGGL(k_rowtab, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, st, ratio, ROW, r0, rows, (uint64_t)0, static_cast<RowBase *>(rt));
     hipLaunchKernelGGL(k_jtab, dim3(2), dim3(256), 0, st, ratio, ROW, static_cast<double2 *>(jt));
     const int so = (std::fabs(ratio) * (double)(abs_off + n) > 268435456.0) ? 1 : 0;
     const uint32_t grid = (uint32_t)(rows < 4096 ? rows : 4096);

@@ -874,6 +874,60 @@ def test_overlapping_windows_without_lowpass_as_interleaved_launches(engine, ora
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [0, 1, 3])
+def test_overlapping_windows_with_a_shift_as_interleaved_launches(engine, oracle, fmt):
+    """`from F shift X sparkfft -width W -stride S`, S | W, no lowpass: W / S interleaved launches of the wave-local kernels (k_spark, or
+    k_spark2's S = W build from 128 points on), launch phi with an NCO row table of its own — rows of 512 samples that start phi S samples
+    into the stream (src/shift.rs:46-54 is a function of the absolute sample index).  Another tiling of the same NCO scheme than the
+    generic kernel's: compared within the NCO's tolerance with it and with the oracle; window sub-ranges on the launches'
+    row grids reproduce the whole run bit for bit, others take the generic kernel."""
+    from quadrs_amd import _ffi
+    bps = {0: 8, 1: 2, 3: 4}[fmt]
+    sr = 21_000_000
+    for W, S, shift in ((64, 16, 280000), (16, 4, -1_234_567), (8, 4, 280000), (128, 64, 280000), (256, 32, 99_000), (1024, 256, 280000), (32, 32 // 2, 5_000_000)):
+        n = 24 * 1024 + 3 * W + 5
+        data = _synth_bytes(fmt, n, 91 * fmt + W + S)
+        ch = oracle.Chain.from_bytes(data, fmt, sr).shift(shift)
+        ref, _ = ch.spark_fft(W, S)
+        for epi, rng_ in ((engine.EPI_NORMS_F32, None), (engine.EPI_GLYPH_U8, (0.01, 0.5) if fmt == 0 else (0.3, 30.0))):
+            kw = dict(shift_hz=shift, width=W, stride=S, epilogue=epi, rng=rng_)
+            j = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_SPECIALISE, **kw)
+            g = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_GENERIC, **kw)
+            R = W // S
+            eligible = (S * bps) % 4 == 0 and W >= 4
+            assert bool(j.info.kernel_flags & 524288) == eligible, (fmt, W, S, j.info.kernel_flags)
+            if eligible:
+                assert j.info.kernel_kind == 2 and bool(j.info.kernel_flags & 1048576) == (W >= 128)
+                assert j.info.tile_windows == R * max(1, 512 // W)
+            a, b = j.run_host(data), g.run_host(data)
+            assert a.shape == b.shape
+            if epi != engine.EPI_NORMS_F32:
+                assert (a != b).mean() <= 2e-3, (fmt, W, S, float((a != b).mean()))      # glyph cells next to a threshold
+                j.close(); g.close()
+                continue
+            for other, what in ((b, "generic"), (ref, "oracle")):
+                assert other.shape == a.shape
+                mx = np.maximum(np.abs(other).max(axis=1, keepdims=True), 1e-30)
+                assert (np.abs(a.astype(np.float64) - other) / np.spacing(mx.astype(np.float32))).max() <= 1.0, (fmt, W, S, what)
+                assert (a.view(np.uint32) == other.astype(np.float32).view(np.uint32)).mean() >= 0.999, (fmt, W, S, what)
+            nw, unit = j.n_windows, j.info.tile_windows
+            for w0 in sorted({unit, 2 * unit, (nw // (2 * unit)) * unit}):
+                if w0 >= nw:
+                    continue
+                for cnt in sorted({1, min(R + 1, nw - w0), nw - w0}):
+                    first, count = j.src_range(w0, cnt)
+                    sub = j.run_host(data[first * bps:(first + count) * bps], w0, cnt, src_first=first)
+                    assert np.array_equal(sub, a[w0:w0 + cnt]), (fmt, W, S, w0, cnt)
+            w0 = unit + 1                                                       # off the row grids: the generic kernel, within the tolerance
+            if w0 < nw:
+                first, count = j.src_range(w0, nw - w0)
+                sub = j.run_host(data[first * bps:(first + count) * bps], w0, nw - w0, src_first=first)
+                mx = np.maximum(np.abs(a[w0:]).max(axis=1, keepdims=True), 1e-30)
+                assert (np.abs(sub.astype(np.float64) - a[w0:]) / np.spacing(mx)).max() <= 1.0, (fmt, W, S, "off-grid range")
+            j.close(); g.close()
+
+
+@pytest.mark.gpu
 def test_random_lowpass_free_shapes(engine, oracle):
     """Random `from F [shift] sparkfft -width W -stride S` chains (every format, W = 1 ... 1024, strides up to 2 W, three sinks, whole
     streams and random window sub-ranges): the plan-time builds of the wave-local family against the generic chain kernel and the oracle."""
