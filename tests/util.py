@@ -193,13 +193,18 @@ def fuzz_nofir_shapes(Q, n_shapes, seed, log=None, oracle=None, stats=None):
         if stats is not None:
             stats.append((int(j.info.kernel_kind), int(j.info.kernel_flags)))
 
+        # bit for bit where the two kernels tile the NCO alike (no shift; cf32 with windows side by side); within the NCO's tolerance where
+        # they do not (8-bit formats and cs16: rows of 512 against 1024 samples; overlapping windows behind a shift: a row grid per
+        # interleaved launch) — DESIGN section 4.  Sinks that quantise then differ in a cell next to a threshold at most.
+        exact = shift is None or (fmt == 0 and S >= W)
+
         def same(x, y):
             if x.shape != y.shape:
                 return False
-            if shift is None or fmt == 0 or x.dtype != np.float32:
-                # (8-bit formats and cs16 with a shift: the wave-local kernels' NCO rows are 512 samples, the generic kernel's 1024 —
-                # two tilings of the same scheme; sinks that quantise are compared through the norms' tolerance below)
-                return x.tobytes() == y.tobytes() if (shift is None or fmt == 0) else True
+            if exact:
+                return x.tobytes() == y.tobytes()
+            if x.dtype != np.float32:
+                return float((x != y).mean()) <= 5e-3
             scale = ulp_of(np.maximum(np.abs(y).max(axis=-1, keepdims=True), 1e-30)).astype(np.float64)
             return bool((np.abs(x.astype(np.float64) - y.astype(np.float64)) <= scale).all())
         ok = same(a, b)
@@ -209,7 +214,7 @@ def fuzz_nofir_shapes(Q, n_shapes, seed, log=None, oracle=None, stats=None):
             cnt = int(rng.integers(1, nw - w0 + 1))
             first, count = j.src_range(w0, cnt)
             sub = j.run_host(raw[first * bps:(first + count) * bps], w0, cnt, src_first=first)
-            ok = sub.tobytes() == a[w0:w0 + cnt].tobytes()
+            ok = same(sub, a[w0:w0 + cnt])
             if not ok:
                 desc += f" SUB-RANGE w0={w0} cnt={cnt}"
         if ok and epi == 0 and oracle is not None and nw > 0:
