@@ -2759,6 +2759,124 @@ __global__ __launch_bounds__(kPipe3Threads, LB) void k_chain_pipe3(const ChainPa
     }
 }
 
+// LDS swizzle of the wave's transform buffer (plan-time builds, widths 8 ... 64).  Unswizzled, the buffer's accesses conflict: the
+// scatter into transposed order 2- to 4-way, the base butterflies' 16-byte pieces (a lane owns a run of `base` points: lane stride 64 or
+// 128 B) 4- to 8-way on every read and write, the first radix-4 layer 2- to 4-way — rocprofv3 on cf32 W = 64 with a shift: the LDS array busy
+// 84 % of the kernel's cycles, 59 % of them conflicts (profiles/r04/nofir_pmc_spark_v1.log).  sigma(p) = p ^ M p with M a GF(2) matrix
+// that only feeds HIGHER index bits into bits 1 ... 4 (a bijection; bit 0 untouched, so 16-byte pieces stay whole; sources >= log2(base),
+// so a run sees one XOR value).  m[d - 1] = the source bits XORed into bit d, found per (W, SPL) by scripts/lds_swizzle_search.py over
+// every LDS instruction of a 512- and a 1024-sample tile under the bank rules of MI355X_MICROARCH.md (lane-group cycles, identity -> map;
+// conflict-free = 1x):
+template <uint32_t W, uint32_t SPL> struct SparkSwz { static constexpr uint32_t m[4] = {0, 0, 0, 0}; };
+template <> struct SparkSwz<64, 2> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };   // 3.30x -> 0.90x (some groups idle)
+template <> struct SparkSwz<32, 2> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x30, 0x40}; };    // 2.78x -> 1.00x
+template <> struct SparkSwz<16, 2> { static constexpr uint32_t m[4] = {0x10, 0x20, 0x40, 0x80}; };   // 4.14x -> 1.14x
+template <> struct SparkSwz<8, 2> { static constexpr uint32_t m[4] = {0x50, 0x20, 0x0, 0x0}; };      // 2.83x -> 1.33x
+template <> struct SparkSwz<64, 4> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };   // 3.10x -> 0.90x
+template <> struct SparkSwz<32, 4> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x20, 0x40}; };    // 2.78x -> 1.00x
+template <> struct SparkSwz<16, 4> { static constexpr uint32_t m[4] = {0x10, 0x20, 0x40, 0x80}; };   // 4.71x -> 1.14x
+template <> struct SparkSwz<8, 4> { static constexpr uint32_t m[4] = {0x50, 0x20, 0x0, 0x0}; };      // 3.50x -> 1.33x
+// SPL = 1: the scatter is a gather of consecutive decimated outputs, one per lane (k_chain_pipe3s's transform stage)
+template <> struct SparkSwz<64, 1> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };   // 3.70x -> 0.90x
+template <> struct SparkSwz<128, 1> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x20, 0x40}; };   // 3.33x -> 1.17x
+template <> struct SparkSwz<32, 1> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x20, 0x40}; };    // 2.78x -> 1.00x
+template <> struct SparkSwz<16, 1> { static constexpr uint32_t m[4] = {0x10, 0x20, 0x40, 0x80}; };   // 3.86x -> 0.86x
+template <> struct SparkSwz<256, 1> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };  // 4.92x -> 1.08x
+template <class SZ> struct SparkSwzFn {
+    // the sources at distance `off` above their destination, as a mask over the destination bits
+    static constexpr uint32_t mask_off(uint32_t off) {
+        uint32_t r = 0;
+        for (uint32_t d = 1; d <= 4; ++d) if ((SZ::m[d - 1] >> (d + off)) & 1u) r |= 1u << d;
+        return r;
+    }
+    // sigma(p) ^ p.  GF(2)-linear: delta(a | b) = delta(a) ^ delta(b) for disjoint a, b — callers split an index into a per-lane part
+    // (formed once per tile) and a compile-time part (folded)
+    static __device__ __forceinline__ constexpr uint32_t delta(uint32_t p) {
+        constexpr uint32_t k1 = mask_off(1), k2 = mask_off(2), k3 = mask_off(3), k4 = mask_off(4), k5 = mask_off(5), k6 = mask_off(6), k7 = mask_off(7), k8 = mask_off(8);
+        return ((p >> 1) & k1) ^ ((p >> 2) & k2) ^ ((p >> 3) & k3) ^ ((p >> 4) & k4) ^ ((p >> 5) & k5) ^ ((p >> 6) & k6) ^ ((p >> 7) & k7) ^ ((p >> 8) & k8);
+    }
+};
+
+// The transform of a wave's tile in the swizzled layout: base butterflies on 16-byte pieces, radix-4 layers in place (W >= 8, compile-time
+// geometry; the arithmetic and its order are wave_fft_epilogue_fn's).  Addresses are LDS BYTE offsets: the buffer starts on a 256-byte
+// boundary (k_spark checks), so the swizzle's XORs (index bits 1 ... 4 = byte bits 4 ... 7) apply to the byte address directly — one v_xor
+// per access on top of a per-lane base, instead of an XOR, a shift and an add.
+typedef float spark_f2n __attribute__((ext_vector_type(2)));
+typedef float spark_f4n __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) spark_f2n spark_lds_f2;
+typedef __attribute__((address_space(3))) spark_f4n spark_lds_f4;
+__device__ __forceinline__ float2 spark_ld2(uint32_t a) { const spark_f2n v = *(const spark_lds_f2 *)(uintptr_t)a; return make_float2(v.x, v.y); }
+__device__ __forceinline__ void spark_st2(uint32_t a, float2 v) { *(spark_lds_f2 *)(uintptr_t)a = spark_f2n{v.x, v.y}; }
+
+template <class GeoT, uint32_t TS, uint32_t SPL, int PART = 3 /* 1: base butterflies; 2: radix-4 layers; 3: both */, bool RT = false /* n_win windows of the buffer hold data (else all TS / W) */>
+__device__ __forceinline__ void spark_fft_swz(const ChainParams &P, const float2 *twl, uint32_t fb /* LDS byte offset of the wave's buffer */, uint32_t lane_in,
+                                              uint32_t n_win = TS / GeoT::W) {
+    using SZ = SparkSwzFn<SparkSwz<GeoT::W, SPL>>;
+    constexpr uint32_t base = GeoT::base_len, lb = GeoT::log_base, layers = GeoT::layers;
+    static_assert(base == 8 || base == 16, "spark_fft_swz: W >= 8");
+    uint32_t lo = lane_in;
+    asm volatile("" : "+v"(lo));            // opaque per tile: addresses are rebuilt, not hoisted out of the tile loop and spilled
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    constexpr uint32_t n_task = TS / base;
+    const uint32_t n_task_rt = n_win << (GeoT::logW - lb);
+    if constexpr ((PART & 1) != 0) {
+#pragma unroll
+    for (uint32_t k = 0; k < (n_task + 63) / 64; ++k) {
+        const uint32_t t = lo + 64 * k;
+        if (RT ? t < n_task_rt : (n_task % 64 == 0 || t < n_task)) {
+            const uint32_t r0 = t << lb, a0 = fb + ((r0 ^ SZ::delta(r0)) << 3);          // piece q of the run sits at a0 ^ 16 q
+            float2 v[base];
+#pragma unroll
+            for (uint32_t q = 0; q < base / 2; ++q) {
+                const spark_f4n pc = *(const spark_lds_f4 *)(uintptr_t)(a0 ^ (16 * q));
+                v[2 * q] = make_float2(pc.x, pc.y); v[2 * q + 1] = make_float2(pc.z, pc.w);
+            }
+            if constexpr (base == 16) bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2); else bf8(v, P.root2);
+            uint32_t a1 = a0;
+            asm volatile("" : "+v"(a1));        // the piece addresses are formed again (one XOR each) instead of held across the butterfly
+#pragma unroll
+            for (uint32_t q = 0; q < base / 2; ++q)
+                *(spark_lds_f4 *)(uintptr_t)(a1 ^ (16 * q)) = spark_f4n{v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y};
+        }
+    }
+    }
+    uint32_t cols = base, log_cols = lb, tw_off = 0;
+    const uint32_t n_bf_rt = n_win << (GeoT::logW - 2);
+    if constexpr ((PART & 2) != 0) {
+#pragma unroll
+    for (uint32_t l = 0; l < layers; ++l) {
+        wsync();
+        // layers of at most 64 columns: a lane's butterflies t = lane + 64 k share i = t mod cols, hence their three twiddles
+        float2 tc1 = make_float2(0.f, 0.f), tc2 = tc1, tc3 = tc1;
+        if (cols <= 64) { const uint32_t i = lo & (cols - 1); tc1 = twl[tw_off + 3 * i]; tc2 = twl[tw_off + 3 * i + 1]; tc3 = twl[tw_off + 3 * i + 2]; }
+#pragma unroll
+        for (uint32_t k = 0; k < (TS / 4 + 63) / 64; ++k) {
+            const uint32_t t = lo + 64 * k, chunk = t >> log_cols, i = t & (cols - 1);
+            if (RT ? t >= n_bf_rt : ((TS / 4) % 64 != 0 && t >= TS / 4)) continue;
+            const uint32_t p0 = chunk * 4 * cols + i, b0 = fb + ((p0 ^ SZ::delta(p0)) << 3);
+            uint32_t dp[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                // q cols: index bits log_cols, log_cols + 1, zero in p0.  Bits below 5 (and the XOR value, bits 1 ... 4) go in by XOR — inside the
+                // low 256 bytes, where the 256-byte-aligned base contributes nothing —, bits from 5 up by addition (an instruction offset)
+                const uint32_t qc = q * cols, lo_q = (qc ^ SZ::delta(qc)) & 31u, hi_q = qc & ~31u;
+                dp[q] = (b0 ^ (lo_q << 3)) + (hi_q << 3);
+            }
+            float2 t1 = tc1, t2 = tc2, t3 = tc3;
+            if (cols > 64) { t1 = twl[tw_off + 3 * i]; t2 = twl[tw_off + 3 * i + 1]; t3 = twl[tw_off + 3 * i + 2]; }
+            float2 s0 = spark_ld2(dp[0]);
+            float2 s1 = cmul(spark_ld2(dp[1]), t1);
+            float2 s2 = cmul(spark_ld2(dp[2]), t2);
+            float2 s3 = cmul(spark_ld2(dp[3]), t3);
+            bf4(s0, s1, s2, s3);
+            spark_st2(dp[0], s0); spark_st2(dp[1], s1); spark_st2(dp[2], s2); spark_st2(dp[3], s3);
+        }
+        tw_off += 3 * cols; cols *= 4; log_cols += 2;
+    }
+    }
+    wsync();
+}
+
 // ---------------------------------------------------------------- the STREAMING three-stage kernel (FixedGeo FLAGS_ bits 15 + 17)
 //
 // k_chain_pipe3 treats tiles as independent: every tile re-reads, re-shifts and re-filters the (W - S) D + T samples it shares with
@@ -2801,8 +2919,16 @@ struct Pipe3S {
                                W <= 64 * 16 && f0 >= 1 && f0 <= GS && f0 > W - S && ntrunc <= S && MIRD * D <= ROW && (G - 1) * S + W <= 2 * GS;
     static constexpr bool kWrite = (GeoT::kFlags & kGeoWriteSink) != 0;          // no FFT stage, no output ring
     static_assert(!kWrite || !kOverlap, "the write sink's sub-blocks lie side by side");
+    // the two transform buffers (base pass of step s beside the layers of step s - 1) start on a 256-byte boundary: their swizzled layout
+    // (SparkSwz) XORs into LDS byte addresses
+    static constexpr uint32_t FBX_OFF = (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + 31u) & ~31u;
     static constexpr uint32_t kLdsBytes = kWrite ? RAW_ELEMS * 8 + ((T + 3) & ~3u) * 4
-                                                 : (RAW_ELEMS + (kOverlap ? 2u : 1u) * DR + 2 * G * W + W) * 8 + ((T + 3) & ~3u) * 4;      // two transform buffers: base pass of step s beside the layers of step s - 1
+                                                 : (FBX_OFF + 2 * G * W + W) * 8 + ((T + 3) & ~3u) * 4;
+    // swizzled transform buffers: the stage's LDS traffic unswizzled is 3.7x its conflict-free cycle count (the base pass's 16-byte pieces
+    // 8-way, the gather and the first layer 2- to 4-way) — a tenth of the LDS array's cycles per step in a kernel whose FIR keeps the array
+    // ~80 % busy (rocprofv3, cfg5).  Needs every wave's half of a buffer on a 256-byte boundary.
+    static constexpr uint32_t GH = (G + 1) / 2;
+    static constexpr bool kSwzFft = !kWrite && W >= 8 && (GH * W) % 32 == 0 && (G * W) % 32 == 0;
     static constexpr uint32_t kConsumerThreads = kWrite ? 256u : 512u;
 };
 
@@ -2823,7 +2949,7 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *raw = reinterpret_cast<float2 *>(smem);
     float2 *dec = raw + K::RAW_ELEMS, *trc = dec + DR;                             // trc exists for overlapping windows only
-    float2 *fbx = dec + (K::kOverlap ? 2u : 1u) * DR;                              // two buffers of G W points, used alternately
+    float2 *fbx = raw + K::FBX_OFF;                                                // two buffers of G W points, used alternately
     float2 *twl = fbx + 2 * (size_t)G * W;
     float *tapl = reinterpret_cast<float *>(kWrite ? raw + K::RAW_ELEMS : twl + W);  // write sink: sample ring | taps, nothing else
     if (P.lds_dyn < K::kLdsBytes) return;                                              // host / kernel layout disagreement: leave the output untouched (the parity tests see it)
@@ -3014,6 +3140,23 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
                         asm volatile("" : "+v"(lane));
                         constexpr uint32_t log_width = 2 * GeoT::layers;
                         const uint32_t n_o = (g1 - g0) << logW;
+                        if constexpr (K::kSwzFft) {
+                            using SZ = SparkSwzFn<SparkSwz<W, 1>>;
+                            const uint32_t fb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)fbw;
+                            for (uint32_t o = lane; o < n_o; o += 64) {
+                                const uint32_t gl_ = o >> logW, k = o & (W - 1);
+                                uint32_t pos = rot + (g0 + gl_) * S + k;
+                                pos = pos >= DR ? pos - DR : pos;
+                                const bool tr = K::kOverlap && (W - k) * D + T / 2 < T;
+                                const float2 val = dec[pos + (tr ? DR : 0u)];
+                                const uint32_t xx = k & ((1u << log_width) - 1), yy = k >> log_width;
+                                const uint32_t idx = (gl_ << logW) + yy + (rev4(xx, GeoT::layers) << GeoT::log_base);
+                                spark_st2(fb + ((idx ^ SZ::delta(idx)) << 3), val);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            spark_fft_swz<GeoT, K::GH * W, 1, 1, true>(P, twl, fb, lane, g1 - g0);
+                        } else {
                         for (uint32_t o = lane; o < n_o; o += 64) {
                             const uint32_t gl_ = o >> logW, k = o & (W - 1);
                             // ring position (s G S + g S + k) mod 3 G S: g S + k < 2 G S (Pipe3S::ok), the step's base rotates through 0, GS, 2GS
@@ -3027,6 +3170,7 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         wave_fft_epilogue_fn<GeoT, 0, 1>(P, geo, twl, fbw, 0, g1 - g0, tid);
+                        }
                     }
                 }
                 if (it >= 3) { rot += GS; rot = rot >= DR ? rot - DR : rot; }
@@ -3035,8 +3179,47 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
                 const uint64_t t = t_lo + s;
                 const uint32_t g_cnt = g_cnt_of(t);
                 const uint32_t g1 = (g0 + GH < g_cnt) ? g0 + GH : g_cnt;
-                if (g0 < g1 && !QD_DBG(P, 128))
-                    wave_fft_epilogue_fn<GeoT, (GH * W + 63) / 64, 2>(P, geo, twl, fbx + (size_t)(s & 1u) * G * W + (size_t)g0 * W, P.first_window + t * G + g0, g1 - g0, tid);
+                if (g0 < g1 && !QD_DBG(P, 128)) {
+                    float2 *fbp = fbx + (size_t)(s & 1u) * G * W + (size_t)g0 * W;
+                    if constexpr (K::kSwzFft) {
+                        using SZ = SparkSwzFn<SparkSwz<W, 1>>;
+                        const uint32_t fb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)fbp;
+                        uint32_t lane = tid & 63u;
+                        asm volatile("" : "+v"(lane));
+                        spark_fft_swz<GeoT, K::GH * W, 1, 2, true>(P, twl, fb, lane, g1 - g0);
+                        // the epilogue of wave_fft_epilogue_fn over the swizzled buffer (src/fft.rs:48-61, :86-97)
+                        const uint64_t wrel = P.first_window + t * G + g0 - P.out_window0;
+                        const uint32_t n_out_s = (g1 - g0) << logW;
+                        if (P.epi == 2) {
+                            constexpr uint32_t KB = (K::GH * W + 63) / 64;
+                            float nm[KB];
+#pragma unroll
+                            for (uint32_t k = 0; k < KB; ++k) { const uint32_t o = lane + 64 * k; nm[k] = o < n_out_s ? norm_ref(spark_ld2(fb + ((o ^ SZ::delta(o)) << 3))) : 0.f; }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                            float *nb = reinterpret_cast<float *>(fbp);
+#pragma unroll
+                            for (uint32_t k = 0; k < KB; ++k) { const uint32_t o = lane + 64 * k; if (o < n_out_s) nb[o] = nm[k]; }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                            for (uint32_t wl = lane; wl < g1 - g0; wl += 64) {
+                                const float *q = nb + (wl << logW);
+                                float first = 0.f, second = 0.f;
+                                for (uint32_t k = 0; k < W / 2; ++k) first = first + q[k];
+                                for (uint32_t k = W / 2; k < W; ++k) second = second + q[k];
+                                reinterpret_cast<uint8_t *>(P.out)[wrel + wl] = first < second ? 0 : 1;
+                            }
+                        } else {
+                            float *outf = reinterpret_cast<float *>(P.out) + (wrel << logW);
+                            uint8_t *outb = reinterpret_cast<uint8_t *>(P.out) + (wrel << logW);
+                            for (uint32_t o = lane; o < n_out_s; o += 64) {
+                                const uint32_t e = o ^ (W >> 1);
+                                const float nm = norm_ref(spark_ld2(fb + ((e ^ SZ::delta(e)) << 3)));
+                                if (P.epi == 0) outf[o] = nm;
+                                else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
+                            }
+                        }
+                    } else
+                    wave_fft_epilogue_fn<GeoT, (GH * W + 63) / 64, 2>(P, geo, twl, fbp, P.first_window + t * G + g0, g1 - g0, tid);
+                }
             }
             __syncthreads();
         }
@@ -3090,110 +3273,6 @@ struct SparkWalk {
         }
     }
 };
-
-// LDS swizzle of the wave's transform buffer (plan-time builds, widths 8 ... 64).  Unswizzled, the buffer's accesses conflict: the
-// scatter into transposed order 2- to 4-way, the base butterflies' 16-byte pieces (a lane owns a run of `base` points: lane stride 64 or
-// 128 B) 4- to 8-way on every read and write, the first radix-4 layer 2- to 4-way — rocprofv3 on cf32 W = 64 with a shift: the LDS array busy
-// 84 % of the kernel's cycles, 59 % of them conflicts (profiles/r04/nofir_pmc_spark_v1.log).  sigma(p) = p ^ M p with M a GF(2) matrix
-// that only feeds HIGHER index bits into bits 1 ... 4 (a bijection; bit 0 untouched, so 16-byte pieces stay whole; sources >= log2(base),
-// so a run sees one XOR value).  m[d - 1] = the source bits XORed into bit d, found per (W, SPL) by scripts/lds_swizzle_search.py over
-// every LDS instruction of a 512- and a 1024-sample tile under the bank rules of MI355X_MICROARCH.md (lane-group cycles, identity -> map;
-// conflict-free = 1x):
-template <uint32_t W, uint32_t SPL> struct SparkSwz { static constexpr uint32_t m[4] = {0, 0, 0, 0}; };
-template <> struct SparkSwz<64, 2> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };   // 3.30x -> 0.90x (some groups idle)
-template <> struct SparkSwz<32, 2> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x30, 0x40}; };    // 2.78x -> 1.00x
-template <> struct SparkSwz<16, 2> { static constexpr uint32_t m[4] = {0x10, 0x20, 0x40, 0x80}; };   // 4.14x -> 1.14x
-template <> struct SparkSwz<8, 2> { static constexpr uint32_t m[4] = {0x50, 0x20, 0x0, 0x0}; };      // 2.83x -> 1.33x
-template <> struct SparkSwz<64, 4> { static constexpr uint32_t m[4] = {0x40, 0x90, 0x20, 0x40}; };   // 3.10x -> 0.90x
-template <> struct SparkSwz<32, 4> { static constexpr uint32_t m[4] = {0x8, 0x10, 0x20, 0x40}; };    // 2.78x -> 1.00x
-template <> struct SparkSwz<16, 4> { static constexpr uint32_t m[4] = {0x10, 0x20, 0x40, 0x80}; };   // 4.71x -> 1.14x
-template <> struct SparkSwz<8, 4> { static constexpr uint32_t m[4] = {0x50, 0x20, 0x0, 0x0}; };      // 3.50x -> 1.33x
-template <class SZ> struct SparkSwzFn {
-    // the sources at distance `off` above their destination, as a mask over the destination bits
-    static constexpr uint32_t mask_off(uint32_t off) {
-        uint32_t r = 0;
-        for (uint32_t d = 1; d <= 4; ++d) if ((SZ::m[d - 1] >> (d + off)) & 1u) r |= 1u << d;
-        return r;
-    }
-    // sigma(p) ^ p.  GF(2)-linear: delta(a | b) = delta(a) ^ delta(b) for disjoint a, b — callers split an index into a per-lane part
-    // (formed once per tile) and a compile-time part (folded)
-    static __device__ __forceinline__ constexpr uint32_t delta(uint32_t p) {
-        constexpr uint32_t k1 = mask_off(1), k2 = mask_off(2), k3 = mask_off(3), k4 = mask_off(4), k5 = mask_off(5), k6 = mask_off(6), k7 = mask_off(7), k8 = mask_off(8);
-        return ((p >> 1) & k1) ^ ((p >> 2) & k2) ^ ((p >> 3) & k3) ^ ((p >> 4) & k4) ^ ((p >> 5) & k5) ^ ((p >> 6) & k6) ^ ((p >> 7) & k7) ^ ((p >> 8) & k8);
-    }
-};
-
-// The transform of a wave's tile in the swizzled layout: base butterflies on 16-byte pieces, radix-4 layers in place (W >= 8, compile-time
-// geometry; the arithmetic and its order are wave_fft_epilogue_fn's).  Addresses are LDS BYTE offsets: the buffer starts on a 256-byte
-// boundary (k_spark checks), so the swizzle's XORs (index bits 1 ... 4 = byte bits 4 ... 7) apply to the byte address directly — one v_xor
-// per access on top of a per-lane base, instead of an XOR, a shift and an add.
-typedef float spark_f2n __attribute__((ext_vector_type(2)));
-typedef float spark_f4n __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) spark_f2n spark_lds_f2;
-typedef __attribute__((address_space(3))) spark_f4n spark_lds_f4;
-__device__ __forceinline__ float2 spark_ld2(uint32_t a) { const spark_f2n v = *(const spark_lds_f2 *)(uintptr_t)a; return make_float2(v.x, v.y); }
-__device__ __forceinline__ void spark_st2(uint32_t a, float2 v) { *(spark_lds_f2 *)(uintptr_t)a = spark_f2n{v.x, v.y}; }
-
-template <class GeoT, uint32_t TS, uint32_t SPL>
-__device__ __forceinline__ void spark_fft_swz(const ChainParams &P, const float2 *twl, uint32_t fb /* LDS byte offset of the wave's buffer */, uint32_t lane_in) {
-    using SZ = SparkSwzFn<SparkSwz<GeoT::W, SPL>>;
-    constexpr uint32_t base = GeoT::base_len, lb = GeoT::log_base, layers = GeoT::layers;
-    static_assert(base == 8 || base == 16, "spark_fft_swz: W >= 8");
-    uint32_t lo = lane_in;
-    asm volatile("" : "+v"(lo));            // opaque per tile: addresses are rebuilt, not hoisted out of the tile loop and spilled
-    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    constexpr uint32_t n_task = TS / base;
-#pragma unroll
-    for (uint32_t k = 0; k < (n_task + 63) / 64; ++k) {
-        const uint32_t t = lo + 64 * k;
-        if (n_task % 64 == 0 || t < n_task) {
-            const uint32_t r0 = t << lb, a0 = fb + ((r0 ^ SZ::delta(r0)) << 3);          // piece q of the run sits at a0 ^ 16 q
-            float2 v[base];
-#pragma unroll
-            for (uint32_t q = 0; q < base / 2; ++q) {
-                const spark_f4n pc = *(const spark_lds_f4 *)(uintptr_t)(a0 ^ (16 * q));
-                v[2 * q] = make_float2(pc.x, pc.y); v[2 * q + 1] = make_float2(pc.z, pc.w);
-            }
-            if constexpr (base == 16) bf16(v, P.tw16_1, P.tw16_2, P.tw16_3, P.root2); else bf8(v, P.root2);
-            uint32_t a1 = a0;
-            asm volatile("" : "+v"(a1));        // the piece addresses are formed again (one XOR each) instead of held across the butterfly
-#pragma unroll
-            for (uint32_t q = 0; q < base / 2; ++q)
-                *(spark_lds_f4 *)(uintptr_t)(a1 ^ (16 * q)) = spark_f4n{v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y};
-        }
-    }
-    uint32_t cols = base, log_cols = lb, tw_off = 0;
-#pragma unroll
-    for (uint32_t l = 0; l < layers; ++l) {
-        wsync();
-        // layers of at most 64 columns: a lane's butterflies t = lane + 64 k share i = t mod cols, hence their three twiddles
-        float2 tc1 = make_float2(0.f, 0.f), tc2 = tc1, tc3 = tc1;
-        if (cols <= 64) { const uint32_t i = lo & (cols - 1); tc1 = twl[tw_off + 3 * i]; tc2 = twl[tw_off + 3 * i + 1]; tc3 = twl[tw_off + 3 * i + 2]; }
-#pragma unroll
-        for (uint32_t k = 0; k < TS / 256; ++k) {
-            const uint32_t t = lo + 64 * k, chunk = t >> log_cols, i = t & (cols - 1);
-            const uint32_t p0 = chunk * 4 * cols + i, b0 = fb + ((p0 ^ SZ::delta(p0)) << 3);
-            uint32_t dp[4];
-#pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                // q cols: index bits log_cols, log_cols + 1, zero in p0.  Bits below 5 (and the XOR value, bits 1 ... 4) go in by XOR — inside the
-                // low 256 bytes, where the 256-byte-aligned base contributes nothing —, bits from 5 up by addition (an instruction offset)
-                const uint32_t qc = q * cols, lo_q = (qc ^ SZ::delta(qc)) & 31u, hi_q = qc & ~31u;
-                dp[q] = (b0 ^ (lo_q << 3)) + (hi_q << 3);
-            }
-            float2 t1 = tc1, t2 = tc2, t3 = tc3;
-            if (cols > 64) { t1 = twl[tw_off + 3 * i]; t2 = twl[tw_off + 3 * i + 1]; t3 = twl[tw_off + 3 * i + 2]; }
-            float2 s0 = spark_ld2(dp[0]);
-            float2 s1 = cmul(spark_ld2(dp[1]), t1);
-            float2 s2 = cmul(spark_ld2(dp[2]), t2);
-            float2 s3 = cmul(spark_ld2(dp[3]), t3);
-            bf4(s0, s1, s2, s3);
-            spark_st2(dp[0], s0); spark_st2(dp[1], s1); spark_st2(dp[2], s2); spark_st2(dp[3], s3);
-        }
-        tw_off += 3 * cols; cols *= 4; log_cols += 2;
-    }
-    wsync();
-}
 
 template <int FMT> struct SparkTraits {
     using FT = FmtTraits<FMT>;

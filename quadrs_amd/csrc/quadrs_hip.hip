@@ -650,7 +650,7 @@ size_t lds_for(uint32_t G, uint64_t W, uint64_t S, uint64_t D, uint64_t T, uint3
         const uint64_t c = T - T / 2, mird = ((c % D) + T + D - 1) / D + 1;
         const uint64_t raw_e = ((ringd + mird) * dp + 1) & ~1ull;
         const uint64_t p3 = (flags & kGeoWriteSink) ? raw_e * 8 + taps_b + 64      // the write sink: sample ring | taps
-                                                    : raw_e * 8 + (S < W ? 2 : 1) * 3 * (uint64_t)G * S * 8 + 2 * (uint64_t)G * W * 8 + W * 8 + taps_b + 64;      // trc: overlapping windows only; two transform buffers
+                                                    : raw_e * 8 + (S < W ? 2 : 1) * 3 * (uint64_t)G * S * 8 + 2 * (uint64_t)G * W * 8 + W * 8 + taps_b + 64 + 256;      // trc: overlapping windows only; two transform buffers, on a 256-byte boundary
         if (main_only) *main_only = (size_t)p3;
         return (size_t)(p3 > generic_b ? p3 : generic_b);
     }
