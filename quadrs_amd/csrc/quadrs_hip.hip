@@ -795,6 +795,35 @@ void free_rowtab(RowTab *t) {
     *t = RowTab{};
 }
 
+// What a chain kernel's parameters take from the PLAN (geometry, constants, device tables); the caller adds the call's slab, window range,
+// output and row table.
+void plan_params(const qd_plan *p, ChainParams *Pp) {
+    ChainParams &P = *Pp;
+    P.W = p->W; P.logW = p->logW; P.S = p->S; P.D = p->D; P.T = p->T;
+    const uint32_t c = p->T - p->T / 2;
+    P.G = p->geo.G; P.Dp = p->geo.Dp;
+    P.dmagic = p->D > 1 ? (uint32_t)((1ull << 32) / p->D + 1) : 0;
+    P.dshift = is_pow2(p->D) ? ilog2(p->D) : 0xffffffffu;
+    P.a0 = c / p->D; P.b0 = c % p->D;
+    uint32_t tfast = p->D + p->T / 2;
+    P.T_fast = tfast < p->T ? tfast : p->T;
+    P.a1 = (c + P.T_fast) / p->D; P.b1 = (c + P.T_fast) % p->D;
+    P.base_len = p->fft.base_len; P.log_base = p->fft.log_base; P.layers = p->fft.layers;
+    P.epi = (uint32_t)p->d.epilogue;
+    P.lds_raw_elems = p->geo.lds_raw_elems;
+    P.rmin = p->d.has_range ? p->d.range_min : 0.08f;     // src/fft.rs:22-23
+    P.rmax = p->d.has_range ? p->d.range_max : 1.0f;
+    P.gstep = (P.rmax - P.rmin) / 7.0f;                   // src/fft.rs:45, f32 like the reference
+    P.root2 = (float)std::sqrt(0.5);
+    P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
+    P.ratio = p->ratio;
+    P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
+    P.row_offsets = p->row_offsets_d; P.window = p->window_d;
+    P.blk_len = p->blk_len ? p->blk_len : p->W; P.blk_sub_mask = p->blk_subs - 1;
+    P.tile_extra = p->tile_extra;
+    P.dbg = p->dbg;                                       // 0 except in development builds (QD_DEBUG_SKIP at plan creation)
+}
+
 // Overlapping windows without a lowpass or a shift, stride S dividing the width (qd_plan::spark_R = W / S): launch phi covers the windows
 // w = phi (mod R) of the range — side by side in the stream that starts phi * S samples later — and writes every R-th output row.
 // (Running the R launches over one 8 ... 128 MiB stretch of the stream after the other, so that the re-reads hit the memory-side cache,
@@ -805,15 +834,9 @@ int launch_spark_phases(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t s
     const uint64_t R = p->spark_R, W = p->W, S = p->S, obw = out_bytes_per_window(p);
     if (tabs->launched) HIPCHK(hipStreamWaitEvent(st, tabs->done, 0));
     ChainParams P{};
-    P.W = p->W; P.logW = p->logW; P.S = p->W; P.D = 1; P.T = 0; P.G = p->geo.G; P.Dp = 1;
-    P.dshift = 0; P.base_len = p->fft.base_len; P.log_base = p->fft.log_base; P.layers = p->fft.layers;
-    P.epi = (uint32_t)p->d.epilogue;
-    P.rmin = p->d.has_range ? p->d.range_min : 0.08f; P.rmax = p->d.has_range ? p->d.range_max : 1.0f;
-    P.gstep = (P.rmax - P.rmin) / 7.0f;
-    P.root2 = (float)std::sqrt(0.5);
-    P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
-    P.tw = p->tw_d; P.blk_len = p->W; P.lds_dyn = (uint32_t)p->geo.lds_main;
-    P.ratio = p->ratio; P.jtab = p->jtab_d;
+    plan_params(p, &P);
+    P.S = p->W;                                 // each launch's own geometry: windows side by side
+    P.lds_dyn = (uint32_t)p->geo.lds_main;
     P.out_row_stride = (uint32_t)R;
     if (p->timing) {
         if (!p->ev_made) { HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1)); p->ev_made = true; }
@@ -886,34 +909,12 @@ int launch_chain(qd_plan *p, NcoTabs *tabs, const void *src_d, uint64_t src_firs
     }
 
     ChainParams P{};
+    plan_params(p, &P);
     P.src = static_cast<const uint8_t *>(src_d);
     P.src_first = src_first; P.src_count = src_count;
     P.out_window0 = out_window0;
-    P.W = p->W; P.logW = p->logW; P.S = p->S; P.D = p->D; P.T = p->T;
-    const uint32_t c = p->T - p->T / 2;
-    P.G = p->geo.G; P.Dp = p->geo.Dp;
-    P.dmagic = p->D > 1 ? (uint32_t)((1ull << 32) / p->D + 1) : 0;
-    P.dshift = is_pow2(p->D) ? ilog2(p->D) : 0xffffffffu;
-    P.a0 = c / p->D; P.b0 = c % p->D;
-    uint32_t tfast = p->D + p->T / 2;
-    P.T_fast = tfast < p->T ? tfast : p->T;
-    P.a1 = (c + P.T_fast) / p->D; P.b1 = (c + P.T_fast) % p->D;
-    P.base_len = p->fft.base_len; P.log_base = p->fft.log_base; P.layers = p->fft.layers;
-    P.epi = (uint32_t)p->d.epilogue;
-    P.lds_raw_elems = p->geo.lds_raw_elems;
-    P.rmin = p->d.has_range ? p->d.range_min : 0.08f;     // src/fft.rs:22-23
-    P.rmax = p->d.has_range ? p->d.range_max : 1.0f;
-    P.gstep = (P.rmax - P.rmin) / 7.0f;                   // src/fft.rs:45, f32 like the reference
-    P.root2 = (float)std::sqrt(0.5);
-    P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
-    P.ratio = p->ratio;
     P.rowtab = tabs->main.d; P.rowtab_row0 = tabs->main.row0;
-    P.jtab = p->jtab_d; P.taps = p->taps_d; P.tw = p->tw_d;
     P.out = out_d;
-    P.row_offsets = p->row_offsets_d; P.window = p->window_d;
-    P.blk_len = p->blk_len ? p->blk_len : p->W; P.blk_sub_mask = p->blk_subs - 1;
-    P.tile_extra = p->tile_extra;
-    P.dbg = p->dbg;                                       // 0 except in development builds (QD_DEBUG_SKIP at plan creation)
 #if defined(QD_STAMP) || defined(QD_WGTIME)
     constexpr size_t kStampWords = 256 + 4 * 4096;
     static unsigned long long *stamps_d = nullptr;
