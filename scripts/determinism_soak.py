@@ -37,3 +37,26 @@ for name, log2, epi, hint in (("cfg3p", 27, 0, None), ("cfg3p", 27, 2, None), ("
             bad += 1
     print(f"{name} epilogue {epi}{' (' + hint + ')' if hint else ''}: kind {p.info.kernel_kind}, flags {p.info.kernel_flags}, {p.n_windows} windows, {runs} runs, differing runs: {bad}", flush=True)
     del src, ref, out
+
+# chains without a lowpass: the wave-local family (plan-time builds; LDS traffic ordered by wave-level fences only)
+for fmt, shift, W, S, epi in ((0, None, 128, 128, 0), (0, 280000, 256, 256, 0), (0, None, 1024, 1024, 2), (1, 280000, 256, 256, 1), (0, 280000, 64, 64, 0), (3, None, 16, 16, 0),
+                              (0, None, 4, 2, 0), (1, None, 8, 4, 1), (0, None, 64, 16, 0), (0, 280000, 64, 16, 0), (0, None, 512, 128, 0), (0, 280000, 1024, 256, 1)):
+    n = 1 << 26
+    src = bench.synth_slab(torch, fmt, 0, n, 0x5EED0002, dev)
+    kw = dict(rng=(0.001, 0.5)) if epi == 1 else {}
+    p = Q.Plan(fmt, 21_000_000, n, shift_hz=shift, width=W, stride=S, epilogue=epi, kernel_policy=Q.KERNEL_SPECIALISE, **kw)
+    shape = (p.n_windows,) if epi == 2 else (p.n_windows, W)
+    dt = torch.float32 if epi == 0 else torch.uint8
+    ref = torch.empty(shape, dtype=dt, device=dev)
+    out = torch.empty(shape, dtype=dt, device=dev)
+    p.run_device(src, ref)
+    torch.cuda.synchronize()
+    bad = 0
+    for r in range(runs):
+        out.zero_()
+        p.run_device(src, out)
+        if not torch.equal(out.view(torch.uint8), ref.view(torch.uint8)):
+            bad += 1
+    print(f"no lowpass fmt {fmt} shift {shift} W {W} S {S} epilogue {epi}: {p.kernel_name()[:48]}, flags {p.info.kernel_flags}, {p.n_windows} windows, {runs} runs, differing runs: {bad}", flush=True)
+    p.close()
+    del src, ref, out
