@@ -610,6 +610,30 @@ def test_sharded_runs_equal_single_device_run(engine, n_shards):
         assert bits_equal(got, want)
 
 
+@pytest.mark.parametrize("n_shards", [3, 8])
+def test_sharded_lowpass_free_plans(engine, n_shards):
+    """The wave-local kernel family behind qd_plan_run_sharded: shards of a lowpass-free chain (windows side by side, overlapping windows as
+    interleaved launches with and without a shift, a window per lane) start on the windows the plan's tile_windows names, so every shard
+    runs the same kernels on the same NCO row grids as the one-device run: the same bytes, seams included."""
+    from quadrs_amd import _ffi
+    from test_gpu_parity import _signal, _to_format
+    n_dev = C.c_int(0)
+    engine._ffi.check(engine._ffi.lib().qd_device_count(C.byref(n_dev)))
+    devices = [g % n_dev.value for g in range(n_shards)]
+    for fmt, shift, W, S, N in ((0, 280000, 256, 256, 700_000), (0, 280000, 64, 16, 500_000), (1, None, 4, 2, 300_000), (3, None, 32, 8, 400_000), (0, None, 512, 128, 900_000)):
+        data = np.frombuffer(_to_format(_signal(np.random.default_rng(N), N), fmt), dtype=np.uint8)
+        kw = dict(shift_hz=shift, width=W, stride=S, kernel_policy=_ffi.KERNEL_SPECIALISE)
+        one = engine.Plan(fmt, 21_000_000, N, **kw)
+        assert one.info.kernel_flags & 524288
+        want = one.run_host(data)
+        p = engine.Plan(fmt, 21_000_000, N, shard_devices=devices, chunk_bytes=1 << 20, **kw)
+        infos = [p.shard_info(g) for g in range(n_shards)]
+        assert infos[0].w0 == 0 and infos[-1].w1 == p.n_windows and all(a.w1 == b.w0 for a, b in zip(infos, infos[1:]))
+        assert all(si.w0 % one.info.tile_windows == 0 for si in infos)
+        assert all(si.halo == W - S for si in infos[:-1] if si.w1 > si.w0)
+        assert bits_equal(p.run_sharded_host(data), want), (fmt, shift, W, S)
+
+
 def test_fine_grained_calls_reuse_workspaces(engine, oracle):
     """One fine-grained call per window, as the read_at shims of INTEGRATION.md make them: no allocation per call (device
     memory in use stays flat once the pool is warm), results unchanged, and qd_set_stream moves the work to a caller's stream."""
