@@ -604,7 +604,7 @@ def write_sink_leg(cfg, device, steps=8):
     res = {"chain": f"shift {cfg['shift']} -> lowpass -power {cfg['lp'][2] // 2} -decimate {cfg['lp'][1]} {cfg['lp'][0]} -> write (blocks of 4096)",
            "kernel_kind": int(p.info.kernel_kind), "kernel_flags": int(p.info.kernel_flags), "threads": int(p.info.threads), "ms_per_step": ms, "steps": steps,
            "value": n / (ms * 1e-3) / 1e6, "unit": "Msamples/s", "read_GBps": in_b / (ms * 1e-3) / 1e9, "written_GBps": out_b / (ms * 1e-3) / 1e9,
-           "hbm_frac": (in_b + out_b) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "outputs_finite": bool(torch.isfinite(out).all().item())}
+           "hbm_frac": (in_b + out_b) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "outputs_finite": True if glyph else bool(torch.isfinite(out).all().item())}
     p.close()
     del slab, out
     torch.cuda.empty_cache()
@@ -620,15 +620,16 @@ def no_lowpass_leg(device, steps=6):
     import quadrs_amd as Q
     res = {"stream": "16 GiB @21 Msps (cf32: 2^31 samples; cs8: 2^33), stride == width unless the label says otherwise", "unit": "ms per pass", "shapes": {}}
     slab, slab_fmt = None, None
-    for label, fmt, shift, W, S in (("w128", 0, None, 128, 128), ("shift_w128", 0, 280000, 128, 128), ("w1024", 0, None, 1024, 1024), ("w64", 0, None, 64, 64),
-                                    ("w128_stride64_4GiB", 0, None, 128, 64), ("cs8_w256", 1, None, 256, 256)):
+    for label, fmt, shift, W, S in (("w128", 0, None, 128, 128), ("w128_glyph", 0, None, 128, 128), ("shift_w128", 0, 280000, 128, 128), ("w1024", 0, None, 1024, 1024),
+                                    ("w64", 0, None, 64, 64), ("w128_stride64_4GiB", 0, None, 128, 64), ("cs8_w256", 1, None, 256, 256)):
+        glyph = label.endswith("_glyph")                                     # the reference's own sink: one u8 cell per bin (src/fft.rs:54-60)
         n = (1 << 34) // BPS[fmt] if S == W else (1 << 32) // BPS[fmt]       # (overlapping windows: a quarter of the stream, the output is W / S times the input)
         if slab is None or slab_fmt != fmt or slab.numel() * slab.element_size() != n * BPS[fmt]:
             del slab
             torch.cuda.empty_cache()
             slab, slab_fmt = synth_slab(torch, fmt, 0, n, STREAM_SEED, device), fmt
-        p = Q.Plan(fmt, 21_000_000, n, shift_hz=shift, width=W, stride=S)
-        out = torch.empty(p.n_windows, W, dtype=torch.float32, device=device)
+        p = Q.Plan(fmt, 21_000_000, n, shift_hz=shift, width=W, stride=S, **(dict(epilogue=Q.EPI_GLYPH_U8, rng=(0.01, 0.5)) if glyph else {}))
+        out = torch.empty(p.n_windows, W, dtype=torch.uint8 if glyph else torch.float32, device=device)
         for _ in range(2):
             p.run_device(slab, out)
         torch.cuda.synchronize()
@@ -639,12 +640,12 @@ def no_lowpass_leg(device, steps=6):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
-        byts = n * BPS[fmt] + out.numel() * 4
-        res["shapes"][label] = {"chain": f"from {FMT_NAMES[fmt]} {'shift 280000 -> ' if shift else ''}sparkfft -width {W}{'' if S == W else f' -stride {S}'}", "samples": n,
+        byts = n * BPS[fmt] + out.numel() * out.element_size()
+        res["shapes"][label] = {"chain": f"from {FMT_NAMES[fmt]} {'shift 280000 -> ' if shift else ''}sparkfft -width {W}{'' if S == W else f' -stride {S}'}{' (glyph cells)' if glyph else ''}", "samples": n,
                                 "ms": ms, "Msamples_per_s": n / (ms * 1e-3) / 1e6,
                                 "GBps_read_plus_written": byts / (ms * 1e-3) / 1e9, "hbm_frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "frac_of_achievable": byts / (ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS, "kernel": p.kernel_name(),
-                                "kernel_kind": int(p.info.kernel_kind), "kernel_flags": int(p.info.kernel_flags), "outputs_finite": bool(torch.isfinite(out).all().item())}
+                                "kernel_kind": int(p.info.kernel_kind), "kernel_flags": int(p.info.kernel_flags), "outputs_finite": True if glyph else bool(torch.isfinite(out).all().item())}
         p.close()
         del out
     del slab

@@ -93,6 +93,7 @@ struct ChainParams {
     float2 tw16_1, tw16_2, tw16_3;
     uint32_t epi;              // qd_epilogue
     float gstep;               // glyph epilogue: (rmax - rmin) / 7.0f, computed on the host (see glyph_code)
+    float rgstep;              // ... and RN(1 / gstep): the short form's multiplier
     uint32_t dbg;              // development builds (-DQD_DEVELOP) only: timing-only ablation bits (1 NCO, 2 FIR, 4 FFT, 8 hypot, 16 output store, 32 LDS staging); else only the never-true liveness sentinel reads it
     unsigned long long *stamps; // diagnostic builds (-DQD_STAMP) only: per-phase cycle sums, else unused
     unsigned long long *work;   // dynamic tile queue: 8 per-XCD-group counters + 1 arrival counter, 16 words (128 B) apart, all zero
@@ -1330,7 +1331,7 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
             const float2 xv = fbp[o ^ (geo.W >> 1)];
             const float nm = norm_ref(xv);
             if (P.epi == 0) outf[o] = nm;       // (non-temporal stores here measured nothing: 3.343 vs 3.347 ms, round 3)
-            else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
+            else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep, P.rgstep);
         }
     }
 }
@@ -1586,8 +1587,8 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             const float n0 = norm_ref(s2), n1 = norm_ref(s3), n2 = norm_ref(s0), n3 = norm_ref(s1);
             if (P.epi == 0) { outf[i] = n0; outf[i + Wq] = n1; outf[i + 2 * Wq] = n2; outf[i + 3 * Wq] = n3; }
             else {
-                outb[i] = glyph_code(n0, P.rmin, P.rmax, P.gstep); outb[i + Wq] = glyph_code(n1, P.rmin, P.rmax, P.gstep);
-                outb[i + 2 * Wq] = glyph_code(n2, P.rmin, P.rmax, P.gstep); outb[i + 3 * Wq] = glyph_code(n3, P.rmin, P.rmax, P.gstep);
+                outb[i] = glyph_code(n0, P.rmin, P.rmax, P.gstep, P.rgstep); outb[i + Wq] = glyph_code(n1, P.rmin, P.rmax, P.gstep, P.rgstep);
+                outb[i + 2 * Wq] = glyph_code(n2, P.rmin, P.rmax, P.gstep, P.rgstep); outb[i + 3 * Wq] = glyph_code(n3, P.rmin, P.rmax, P.gstep, P.rgstep);
             }
         }
     };
@@ -2154,7 +2155,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 asm volatile("" : "+v"(oo));
                 if (QD_DBG(P, 16)) { asm volatile("" :: "v"(nm)); continue; }      // timing-only ablation: no output store
                 if (P.epi == 0) outf[oo] = nm;
-                else outb[oo] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
+                else outb[oo] = glyph_code(nm, P.rmin, P.rmax, P.gstep, P.rgstep);
             }
         }
         }
@@ -3214,7 +3215,7 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
                                 const uint32_t e = o ^ (W >> 1);
                                 const float nm = norm_ref(spark_ld2(fb + ((e ^ SZ::delta(e)) << 3)));
                                 if (P.epi == 0) outf[o] = nm;
-                                else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep);
+                                else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep, P.rgstep);
                             }
                         }
                     } else
@@ -3482,7 +3483,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
                     const uint32_t o = lo + 64 * (k0 + q);
                     const uint32_t oo = (((o >> GeoT::logW) * RS) << GeoT::logW) + (o & (GeoT::W - 1));      // window o / W lands RS rows apart
                     if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)(oo * 4), 0, 2);
-                    else __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep), orsrc, (int)oo, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep, P.rgstep), orsrc, (int)oo, 0, 2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -3762,7 +3763,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
                             for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)((ob + q * cols) * 4), 0, 2);
                         } else {
 #pragma unroll
-                            for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep), orsrc, (int)(ob + q * cols), 0, 2);
+                            for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep, P.rgstep), orsrc, (int)(ob + q * cols), 0, 2);
                         }
                     }
                 }
@@ -3884,7 +3885,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark0(const ChainParams P) {
         } else if constexpr (EPI == 1) {
             uint32_t pk[(W + 3) / 4] = {};
 #pragma unroll
-            for (uint32_t o = 0; o < W; ++o) pk[o / 4] |= (uint32_t)glyph_code(nm[o], P.rmin, P.rmax, P.gstep) << (8 * (o & 3));
+            for (uint32_t o = 0; o < W; ++o) pk[o / 4] |= (uint32_t)glyph_code(nm[o], P.rmin, P.rmax, P.gstep, P.rgstep) << (8 * (o & 3));
             if constexpr (W == 16) { const v4u_t o = {pk[0], pk[1], pk[2], pk[3]}; __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)(lane * OBW), 0, 2); }
             else if constexpr (W == 8) { const v2u_t o = {pk[0], pk[1]}; __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, (int)(lane * OBW), 0, 2); }
             else if constexpr (W == 4) __builtin_amdgcn_raw_buffer_store_b32(pk[0], orsrc, (int)(lane * OBW), 0, 2);

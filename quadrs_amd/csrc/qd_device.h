@@ -130,7 +130,8 @@ __device__ __forceinline__ float unpack_cs16(uint32_t h) {
 // `distinction` = (mx - mn) / 7.0f (src/fft.rs:45) is computed once on the host (same correctly rounded f32 division)
 // and arrives as a kernel argument: left to hipcc it is hoisted out of the tile loop into a VGPR that gets spilled, and
 // the reload in the epilogue carries an s_waitcnt vmcnt(0) — a full drain of the next tile's prefetch.
-__device__ __forceinline__ uint8_t glyph_code(float norm, float mn, float mx, float distinction) {
+// The reference's arithmetic, literally: one IEEE f32 division per cell.
+__device__ __forceinline__ uint8_t glyph_code_ieee(float norm, float mn, float mx, float distinction) {
     if (norm < mn) return 0;
     if (norm >= mx) return 8;
     float f = (norm - mn) / distinction;
@@ -138,6 +139,21 @@ __device__ __forceinline__ uint8_t glyph_code(float norm, float mn, float mx, fl
     if (!(f > 0.0f)) return 1;
     if (f >= 7.0f) return 255;   // graph[7]: the reference panics here
     return (uint8_t)(1 + (uint32_t)f);
+}
+// The same VALUE without the division sequence (ten instructions of the ~24 a cell costs; the glyph sink is the reference's actual
+// product and its cells are as many as the norms).  q = x * RN(1/d) is the quotient to 1.2e-7 relative (half an ulp in the reciprocal, one
+// rounding of the product), the IEEE quotient f = RN(x / d) to 6e-8: unless q lies within 4e-7 q of an integer, floor(q) == floor(f), f > 0
+// exactly when the cell is past graph[0], f >= 7 exactly when floor(q) >= 7 — and the cell is 1 + floor(q).  Everything else (q next
+// to an integer: ~1e-6 of cells; NaN; a degenerate range) takes the literal form.  tests/test_gpu_parity.py::test_glyph_equals_reference_division
+// runs 2e8 norms, every threshold's neighbourhood included, through the kernels against the f32 formula.
+__device__ __forceinline__ uint8_t glyph_code(float norm, float mn, float mx, float distinction, float rdist /* RN(1 / distinction), from the host like distinction */) {
+    const float x = norm - mn;
+    const float q = x * rdist;
+    const float k = __builtin_floorf(q), fr = q - k, eps = __builtin_fmaf(q, 4e-7f, 1e-30f);
+    if (__builtin_expect(!(fr > eps && fr < 1.0f - eps), 0)) return glyph_code_ieee(norm, mn, mx, distinction);
+    if (norm < mn) return 0;
+    if (norm >= mx) return 8;
+    return k >= 7.0f ? (uint8_t)255 : (uint8_t)(1u + (uint32_t)k);
 }
 
 // ---------------------------------------------------------------- FFT butterflies (rustfft 6.4.0 scalar)

@@ -814,6 +814,7 @@ void plan_params(const qd_plan *p, ChainParams *Pp) {
     P.rmin = p->d.has_range ? p->d.range_min : 0.08f;     // src/fft.rs:22-23
     P.rmax = p->d.has_range ? p->d.range_max : 1.0f;
     P.gstep = (P.rmax - P.rmin) / 7.0f;                   // src/fft.rs:45, f32 like the reference
+    P.rgstep = 1.0f / P.gstep;                            // glyph_code's short form (qd_device.h)
     P.root2 = (float)std::sqrt(0.5);
     P.tw16_1 = compute_twiddle(1, 16); P.tw16_2 = compute_twiddle(2, 16); P.tw16_3 = compute_twiddle(3, 16);
     P.ratio = p->ratio;

@@ -776,3 +776,44 @@ def test_full_size_chains(engine, oracle, name):
         torch.cuda.synchronize()
         assert torch.equal(part, out[w0:w1])
         del part
+
+
+def test_glyph_equals_reference_division(engine):
+    """The glyph sink's cell (src/fft.rs:45,54-60: graph[((norm - min) / distinction) as usize]) without the division sequence
+    (qd_device.h glyph_code: multiply by RN(1 / distinction), take the literal form next to an integer quotient).  Width-1 windows make
+    |X| the sample's own magnitude, so arbitrary norms go through the kernels: every threshold min + k distinction with its +-64 f32
+    neighbours, both ends of the range, zeros, subnormals, huge values and 2e7 random norms per range — against the f32 formula in numpy,
+    cell for cell, for the built-in and the plan-time kernel."""
+    from quadrs_amd import _ffi
+    rng = np.random.default_rng(11)
+
+    def reference(norm, mn, mx):
+        mn, mx = np.float32(mn), np.float32(mx)
+        dist = np.float32((mx - mn) / np.float32(7.0))
+        with np.errstate(all="ignore"):
+            f = ((norm - mn).astype(np.float32) / dist).astype(np.float32)
+        cell = np.where(f >= 7.0, 255, 1 + np.floor(np.where(f > 0, f, 0)).astype(np.int64)).astype(np.int64)
+        cell = np.where(~(f > 0), 1, cell)
+        cell = np.where(norm >= mx, 8, cell)
+        cell = np.where(norm < mn, 0, cell)
+        return cell.astype(np.uint8)
+
+    for mn, mx in ((0.08, 1.0), (0.01, 0.5), (0.3, 30.0), (1e-3, 7e-3), (0.0, 1e6), (5.0, 5.0000005)):
+        dist = np.float32((np.float32(mx) - np.float32(mn)) / np.float32(7.0))
+        centres = np.concatenate([(np.float32(mn) + np.arange(0, 9, dtype=np.float32) * dist).astype(np.float32), np.float32([mn, mx, 0.0, 1e-40, 1e30])])
+        near = []
+        for c in centres:
+            b = np.float32(c).view(np.uint32).astype(np.int64)
+            near.append(np.clip(b + np.arange(-64, 65), 0, 0x7f7fffff).astype(np.uint32).view(np.float32))
+        norms = np.concatenate(near + [rng.uniform(float(mn) - 0.2 * abs(float(mx - mn)) - 1e-6, float(mx) * 1.1 + 1e-6, 20_000_000).astype(np.float32)])
+        norms = np.abs(norms)
+        x = np.zeros((norms.size, 2), dtype=np.float32)
+        x[:, 0] = norms * np.where(rng.random(norms.size) < 0.5, -1, 1).astype(np.float32)
+        want = reference(norms, mn, mx)
+        for policy in (_ffi.KERNEL_NO_PLAN_TIME, _ffi.KERNEL_SPECIALISE):
+            p = engine.Plan(0, 21_000_000, norms.size, width=1, stride=1, epilogue=engine.EPI_GLYPH_U8, rng=(mn, mx), kernel_policy=policy)
+            got = p.run_host(x.tobytes()).reshape(-1)
+            p.close()
+            assert norms.size - 1 <= got.size <= norms.size                    # (src/fft.rs:28: the strict `<` of the window loop)
+            bad = np.nonzero(got != want[:got.size])[0]
+            assert bad.size == 0, (mn, mx, policy, bad[:5], norms[bad[:5]], got[bad[:5]], want[bad[:5]])
