@@ -121,6 +121,14 @@ struct ChainParams {
                                // phi, phi + R, phi + 2R ... (R = W / S), which lie side by side in the stream shifted by phi * S samples
 };
 
+// The glyph cell of a norm: the short form (qd_device.h) in the shape-specialised kernels; the runtime-geometry kernels keep the literal
+// division — they have no scalar register to spare for one more kernel argument (test_builtin_kernels_do_not_spill bounds their spills).
+template <class GeoT>
+__device__ __forceinline__ uint8_t glyph_of(const ChainParams &P, float nm) {
+    if constexpr (GeoT::kFixed) return glyph_code(nm, P.rmin, P.rmax, P.gstep, P.rgstep);
+    else return glyph_code_ieee(nm, P.rmin, P.rmax, P.gstep);
+}
+
 // ---------------------------------------------------------------- geometry policies
 
 constexpr uint32_t ct_log2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) ++l; return l; }
@@ -1331,7 +1339,7 @@ __device__ __forceinline__ void wave_fft_epilogue_fn(const ChainParams &P, const
             const float2 xv = fbp[o ^ (geo.W >> 1)];
             const float nm = norm_ref(xv);
             if (P.epi == 0) outf[o] = nm;       // (non-temporal stores here measured nothing: 3.343 vs 3.347 ms, round 3)
-            else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep, P.rgstep);
+            else outb[o] = glyph_of<GeoT>(P, nm);
         }
     }
 }
@@ -1587,8 +1595,8 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
             const float n0 = norm_ref(s2), n1 = norm_ref(s3), n2 = norm_ref(s0), n3 = norm_ref(s1);
             if (P.epi == 0) { outf[i] = n0; outf[i + Wq] = n1; outf[i + 2 * Wq] = n2; outf[i + 3 * Wq] = n3; }
             else {
-                outb[i] = glyph_code(n0, P.rmin, P.rmax, P.gstep, P.rgstep); outb[i + Wq] = glyph_code(n1, P.rmin, P.rmax, P.gstep, P.rgstep);
-                outb[i + 2 * Wq] = glyph_code(n2, P.rmin, P.rmax, P.gstep, P.rgstep); outb[i + 3 * Wq] = glyph_code(n3, P.rmin, P.rmax, P.gstep, P.rgstep);
+                outb[i] = glyph_of<GeoT>(P, n0); outb[i + Wq] = glyph_of<GeoT>(P, n1);
+                outb[i + 2 * Wq] = glyph_of<GeoT>(P, n2); outb[i + 3 * Wq] = glyph_of<GeoT>(P, n3);
             }
         }
     };
@@ -2155,7 +2163,7 @@ __global__ __launch_bounds__(NT, LB) void k_chain(const ChainParams P) {
                 asm volatile("" : "+v"(oo));
                 if (QD_DBG(P, 16)) { asm volatile("" :: "v"(nm)); continue; }      // timing-only ablation: no output store
                 if (P.epi == 0) outf[oo] = nm;
-                else outb[oo] = glyph_code(nm, P.rmin, P.rmax, P.gstep, P.rgstep);
+                else outb[oo] = glyph_of<GeoT>(P, nm);
             }
         }
         }
@@ -3215,7 +3223,7 @@ __global__ __launch_bounds__(PT_ + ((GeoT::kFlags & kGeoWriteSink) ? 256 : 512),
                                 const uint32_t e = o ^ (W >> 1);
                                 const float nm = norm_ref(spark_ld2(fb + ((e ^ SZ::delta(e)) << 3)));
                                 if (P.epi == 0) outf[o] = nm;
-                                else outb[o] = glyph_code(nm, P.rmin, P.rmax, P.gstep, P.rgstep);
+                                else outb[o] = glyph_of<GeoT>(P, nm);
                             }
                         }
                     } else
@@ -3483,7 +3491,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
                     const uint32_t o = lo + 64 * (k0 + q);
                     const uint32_t oo = (((o >> GeoT::logW) * RS) << GeoT::logW) + (o & (GeoT::W - 1));      // window o / W lands RS rows apart
                     if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)(oo * 4), 0, 2);
-                    else __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep, P.rgstep), orsrc, (int)oo, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b8(glyph_of<GeoT>(P, nm[q]), orsrc, (int)oo, 0, 2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -3763,7 +3771,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark2(const ChainParams P) {
                             for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nm[q]), orsrc, (int)((ob + q * cols) * 4), 0, 2);
                         } else {
 #pragma unroll
-                            for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b8(glyph_code(nm[q], P.rmin, P.rmax, P.gstep, P.rgstep), orsrc, (int)(ob + q * cols), 0, 2);
+                            for (uint32_t q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b8(glyph_of<GeoT>(P, nm[q]), orsrc, (int)(ob + q * cols), 0, 2);
                         }
                     }
                 }
@@ -3885,7 +3893,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark0(const ChainParams P) {
         } else if constexpr (EPI == 1) {
             uint32_t pk[(W + 3) / 4] = {};
 #pragma unroll
-            for (uint32_t o = 0; o < W; ++o) pk[o / 4] |= (uint32_t)glyph_code(nm[o], P.rmin, P.rmax, P.gstep, P.rgstep) << (8 * (o & 3));
+            for (uint32_t o = 0; o < W; ++o) pk[o / 4] |= (uint32_t)glyph_of<GeoT>(P, nm[o]) << (8 * (o & 3));
             if constexpr (W == 16) { const v4u_t o = {pk[0], pk[1], pk[2], pk[3]}; __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)(lane * OBW), 0, 2); }
             else if constexpr (W == 8) { const v2u_t o = {pk[0], pk[1]}; __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, (int)(lane * OBW), 0, 2); }
             else if constexpr (W == 4) __builtin_amdgcn_raw_buffer_store_b32(pk[0], orsrc, (int)(lane * OBW), 0, 2);
