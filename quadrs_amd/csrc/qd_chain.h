@@ -3283,6 +3283,8 @@ struct SparkWalk {
     }
 };
 
+template <class GeoT, bool F = GeoT::kFixed> struct W_CT_GE8 { static constexpr bool value = false; };      // a compile-time width of at least 8
+template <class GeoT> struct W_CT_GE8<GeoT, true> { static constexpr bool value = GeoT::W >= 8; };
 template <int FMT> struct SparkTraits {
     using FT = FmtTraits<FMT>;
     static constexpr uint32_t SPL = FT::SPL, CH = 64u * SPL, RQ = kSparkRow / CH;       // chunk: one wave-wide load; RQ chunks per NCO row
@@ -3332,7 +3334,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
             }
     }
     // plan-time builds with the sink known (the lean path below), W >= 8: the transform buffer in the swizzled layout (SparkSwz)
-    constexpr bool kLeanEpi = GeoT::kFixed && (EPI == 0 || EPI == 1);
+    constexpr bool kLeanEpi = GeoT::kFixed && (EPI == 0 || EPI == 1 || EPI == 2);
     const uint32_t fb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)fbw;      // LDS byte offset of the wave's buffer
     if (kLeanEpi && (fb_off & 255u)) __builtin_trap();                      // (dynamic LDS starts at offset 0: never taken; the swizzled addressing relies on it)
     if constexpr (kLeanEpi) {
@@ -3391,12 +3393,15 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
     // the tile loop — the output goes through a per-tile buffer descriptor that ends with the tile's last valid window —, four |X| per
     // IEEE-path test, non-temporal stores, and the loop's entry edge issues as many (dropped) stores as a tile does so that the waits
     // for the prefetched chunks stay counted instead of vmcnt(0).
-    constexpr bool kLean = GeoT::kFixed && (EPI == 0 || EPI == 1);
+    // (the bucket sink, EPI 2, takes the lean path from W = 8 on: swizzled transform, norms parked as floats, one lane per window sums the
+    // halves in order, the digit through the same range-checked descriptor — one store instruction per 64 windows of the tile)
+    constexpr bool kLean = GeoT::kFixed && (EPI == 0 || EPI == 1 || (EPI == 2 && GeoT::kFixed && W_CT_GE8<GeoT>::value));
     constexpr uint32_t NB = TS / 64;                                       // bins per lane and tile
     if constexpr (kLean) {
         const auto none = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out), 0, 0, 0x00020000);
+        constexpr uint32_t NDUM = EPI == 2 ? ((TS >> GeoT::logW) + 63) / 64 : NB;
 #pragma unroll
-        for (uint32_t q = 0; q < NB; ++q) {
+        for (uint32_t q = 0; q < NDUM; ++q) {
             if constexpr (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(0u, none, (int)(lane * 4 + q * 256), 0, 2);
             else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, none, (int)(lane + q * 64), 0, 2);
         }
@@ -3460,6 +3465,40 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
             // every window of the tile (rows past the slab read as zeros): compile-time trip counts
             if constexpr (GeoT::W >= 8) spark_fft_swz<GeoT, TS, (uint32_t)SPL>(P, twl, fb_off, lane);
             else wave_fft_epilogue_fn<GeoT, 0, 3>(P, geo, twl, fbw, w0, G, tid);
+            if constexpr (EPI == 2) {
+                // freq_levels (src/fft.rs:86-97): |X| of every bin in its own order, parked as floats over the transform buffer, then one lane
+                // per window sums the two halves sequentially
+                using SZB = SparkSwzFn<SparkSwz<GeoT::W, (uint32_t)SPL>>;
+                uint32_t lo = lane;
+                asm volatile("" : "+v"(lo));
+                const uint32_t b0 = fb_off + ((lo ^ SZB::delta(lo)) << 3);
+                float nmv[NB];
+#pragma unroll
+                for (uint32_t k = 0; k < NB; ++k) {
+                    const uint32_t ec = 64 * k;
+                    nmv[k] = norm_ref(spark_ld2((b0 ^ (SZB::delta(ec) << 3)) + (ec << 3)));
+                }
+                wsync();
+                float *nb = reinterpret_cast<float *>(fbw);
+#pragma unroll
+                for (uint32_t k = 0; k < NB; ++k) nb[lo + 64 * k] = nmv[k];
+                wsync();
+                constexpr uint32_t GT = TS >> GeoT::logW;                   // windows per tile
+                const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0), 0, g_cnt, 0x00020000);
+#pragma unroll
+                for (uint32_t wl0 = 0; wl0 < GT; wl0 += 64) {
+                    const uint32_t wl = wl0 + lo;
+                    uint8_t digit = 0;
+                    if (wl < GT) {
+                        const float *q = nb + (wl << GeoT::logW);
+                        float first = 0.f, second = 0.f;
+                        for (uint32_t k = 0; k < GeoT::W / 2; ++k) first = first + q[k];
+                        for (uint32_t k = GeoT::W / 2; k < GeoT::W; ++k) second = second + q[k];
+                        digit = first < second ? 0 : 1;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b8(digit, orsrc, (int)(wl < GT ? wl : 0xffffffu), 0, 2);      // lanes without a window: past the descriptor's end
+                }
+            } else {
             constexpr uint32_t OBW = EPI == 0 ? 4u * GeoT::W : GeoT::W;
             const uint32_t RS = P.out_row_stride ? P.out_row_stride : 1u;      // rows between this launch's windows (interleaved launches of overlapping windows)
             const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(P.out) + (w0 - P.out_window0) * RS * OBW, 0,
@@ -3494,6 +3533,7 @@ __global__ __launch_bounds__(kThreads, LB) void k_spark(const ChainParams P) {
                     else __builtin_amdgcn_raw_buffer_store_b8(glyph_of<GeoT>(P, nm[q]), orsrc, (int)oo, 0, 2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
         } else
         wave_fft_epilogue_fn<GeoT, TS / 64>(P, geo, twl, fbw, w0, g_cnt, tid);
