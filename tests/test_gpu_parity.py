@@ -792,7 +792,8 @@ def test_glyph_equals_reference_division(engine):
         dist = np.float32((mx - mn) / np.float32(7.0))
         with np.errstate(all="ignore"):
             f = ((norm - mn).astype(np.float32) / dist).astype(np.float32)
-        cell = np.where(f >= 7.0, 255, 1 + np.floor(np.where(f > 0, f, 0)).astype(np.int64)).astype(np.int64)
+        with np.errstate(all="ignore"):
+            cell = np.where(f >= 7.0, 255, 1 + np.floor(np.where(f > 0, np.minimum(f, np.float32(8.0)), 0)).astype(np.int64)).astype(np.int64)
         cell = np.where(~(f > 0), 1, cell)
         cell = np.where(norm >= mx, 8, cell)
         cell = np.where(norm < mn, 0, cell)
