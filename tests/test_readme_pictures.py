@@ -13,6 +13,9 @@ What they pin:
     tap count reproduces them exactly, just as the `uniq -c` excerpt at README.md:135-140 no longer matches.
     Today's code agrees with them in 88-99.5 % of the cells at the best alignment, the tones in the same columns.  Kept as
     lower bounds on that agreement plus a strict xfail on exact equality, so a change of either side shows.
+    (Round 4 looked for a parameter that would explain fsk-3, the worst one: other shift values only move the agreement with the
+    bin grid (period sr / 16 / 128 = 10.25 kHz: 4192 cells at 270 kHz against 3917 at the README's 280 kHz), and reading the crop at a
+    circular column offset of 2 instead of 0 / 1 gives 4204 of 4445 — better, still not the picture.  No setting of today's code draws it.)
 """
 import os
 
