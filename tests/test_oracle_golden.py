@@ -25,6 +25,20 @@ def test_readme_ook_string(oracle, cupboard):
     assert ook_pipeline(text) == README_OOK
 
 
+def test_readme_ook_run_lengths(oracle, cupboard):
+    """README.md:128-140: the sed / `uniq -c` excerpt of the same output — `8 . / 8 X / 16 . / 17 X / 15 . / 16 X` between two
+    elisions.  (The survey compared it with the FIRST 16-long run of the output, found `16 9 7 16` there and called the excerpt stale;
+    the elisions allow any place, and it occurs, exactly once, further down: one more reference-held known answer for the chain
+    without a lowpass — window loop, 4-point transform, hypot and the blank threshold over 110 consecutive output lines.)"""
+    lines = oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400).spark_text(4, 2, (0.001, 0.01)).decode().split("\n")[1:-1]
+    import re
+    marks = ["." if re.fullmatch(r".    .", ln) else "X" for ln in lines]          # s/^.    .$/./; s/....*/X/
+    runs = [(k, len(list(grp))) for k, grp in __import__("itertools").groupby(marks)]
+    want = [(".", 8), ("X", 8), (".", 16), ("X", 17), (".", 15), ("X", 16)]
+    hits = [i for i in range(len(runs) - len(want) + 1) if runs[i:i + len(want)] == want]
+    assert len(hits) == 1, (hits, runs)
+
+
 def test_readme_ook_decodes_to_24_6_degrees(oracle, cupboard):
     """README.md:181-187: bytes 00011000 (24) and 10011001 (153)."""
     import re

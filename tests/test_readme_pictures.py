@@ -10,7 +10,8 @@ What they pin:
     loop, the 128-point Radix4 FFT (base 8 + two radix-4 layers), hypot and the glyph ladder, on real data;
   * ook-1 (-width 4 -stride 2 -range 0.001:0.01): 79 rows x 4 bins, every one equal (beside the README string at :167);
   * fsk-2..5 (the chains with `lowpass`): the pictures were taken with an EARLIER revision of the reference's filter code — no
-    tap count reproduces them exactly, just as the `uniq -c` excerpt at README.md:135-140 no longer matches.
+    tap count, cutoff or decimation phase reproduces them exactly.  (SURVEY section 4 lists the `uniq -c` excerpt at README.md:135-140
+    as stale too; it is not — tests/test_oracle_golden.py::test_readme_ook_run_lengths finds it in today's output.)
     Today's code agrees with them in 94.6-99.5 % of the cells at the best alignment, the tones in the same columns, and EVERY
     differing cell differs by exactly one glyph level (the oracle's norm there lies within 0.52 of a glyph step of a threshold,
     median 0.03-0.2).  Kept as exact counts of that agreement plus a strict xfail on exact equality, so a change of either side shows.
@@ -125,7 +126,7 @@ def test_lowpass_pictures_agree_as_far_as_todays_reference_does(oracle, grids, r
     assert len(top(lit_pic) & top(lit_now)) >= 1, (top(lit_pic), top(lit_now))
 
 
-@pytest.mark.xfail(strict=True, reason="README pictures fsk-2..5 predate today's lowpass code (as README.md:135-140 does): 48 / 241 / 50 / 15 cells differ, each by one glyph level")
+@pytest.mark.xfail(strict=True, reason="README pictures fsk-2..5 predate today's lowpass code: 48 / 241 / 50 / 15 cells differ, each by one glyph level")
 @pytest.mark.parametrize("name", ["fsk_2", "fsk_3", "fsk_4", "fsk_5"])
 def test_lowpass_pictures_exactly(oracle, grids, recordings, name):
     norms, codes = oracle_codes(oracle, recordings, name)
