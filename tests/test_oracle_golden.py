@@ -45,8 +45,13 @@ def test_readme_ook_decodes_to_24_6_degrees(oracle, cupboard):
     ab = ook_pipeline(oracle.Chain.from_bytes(cupboard, oracle.FMT_CF32, 400).spark_text(4, 2, (0.001, 0.01)))
     pairs = re.sub(r".*BBBBABAB(AB)*BABA", "", ab)
     pairs = re.sub(r"(..)", r"\1_", pairs)
+    # README.md:172, the `pairs` line, whole (its trailing `%` is the shell's no-newline mark)
+    assert pairs == "AB_AB_AB_BA_BA_AB_AB_AB_AB_BA_AB_AB_BA_BA_AB_AB_BA_AB_BA_AB_AB_AB_AB_AB_AB_BA_AB_BA_BB_BB_BB_BB_BB_BB_Bo_oo_"
     bits = pairs.replace("AB_", "0").replace("BA_", "1")
     assert bits.startswith("00011000" + "0" + "10011001")
+    # README.md:178, the line with the byte boundaries, whole (the README's copy lacks the last `_`)
+    marked = re.sub(r"(.{8})(.)", r"\1^\2^", bits)
+    assert marked.rstrip("_") == "00011000^0^10011001^0^10000001^0^1BB_BB_B^B^_BB_BB_B^B^_Bo_oo"
 
 
 def test_default_range_blanks_cfg1(oracle, cupboard):
