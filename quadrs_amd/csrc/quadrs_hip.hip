@@ -1821,8 +1821,14 @@ int run_host(qd_plan *p, const void *src, int src_mem, uint64_t src_first, uint6
         uint64_t a = ROW, b = step % ROW; while (b) { const uint64_t t = a % b; a = b; b = t; }
         const uint64_t wa = ROW / a;                                    // windows per row-grid period
         uint64_t g = p->geo.G, h = wa; while (h) { const uint64_t t = g % h; g = h; h = t; }
-        const uint64_t unit = (uint64_t)p->geo.G / g * wa;              // lcm
-        if (first_window % wa == 0 && cw >= unit) cw = (cw / unit) * unit;
+        uint64_t unit = (uint64_t)p->geo.G / g * wa;                    // lcm
+        uint64_t grid = wa;
+        if (p->spark_R > 1) {                                           // interleaved launches: chunks start where every launch's first window sits on its grid
+            uint64_t a2 = unit, b2 = p->phase_unit; while (b2) { const uint64_t t = a2 % b2; a2 = b2; b2 = t; }
+            unit = unit / a2 * p->phase_unit;
+            grid = p->phase_unit;
+        }
+        if (first_window % grid == 0 && cw >= unit) cw = (cw / unit) * unit;
     }
     if (cw > n_windows) cw = n_windows ? n_windows : 1;
     const size_t in_bytes = (size_t)(((cw - 1) * step + rpw + 8) * bps), ob = (size_t)(cw * obw);

@@ -934,6 +934,10 @@ def test_overlapping_windows_with_a_shift_as_interleaved_launches(engine, oracle
                 mx = np.maximum(np.abs(other).max(axis=1, keepdims=True), 1e-30)
                 assert (np.abs(a.astype(np.float64) - other) / np.spacing(mx.astype(np.float32))).max() <= 1.0, (fmt, W, S, what)
                 assert (a.view(np.uint32) == other.astype(np.float32).view(np.uint32)).mean() >= 0.999, (fmt, W, S, what)
+            # the host path in many chunks: chunk boundaries fall on the launches' row grids, so the bytes are the one-chunk run's
+            jc = engine.Plan(fmt, sr, n, kernel_policy=_ffi.KERNEL_SPECIALISE, chunk_bytes=1 << 16, **kw)
+            assert np.array_equal(jc.run_host(data), a), (fmt, W, S, "chunked host path")
+            jc.close()
             nw, unit = j.n_windows, j.info.tile_windows
             for w0 in sorted({unit, 2 * unit, (nw // (2 * unit)) * unit}):
                 if w0 >= nw:
